@@ -1,0 +1,171 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is shipped or called by the
+// product path (marl-hideandseek_amd/); only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may build/load it.
+//
+// PARITY UNPINNED: the reference's arithmetic for vectors/quaternions/AABBs lives in the
+// Madrona engine (external/madrona, an empty submodule directory in the reference snapshot,
+// pinned commit unknown).  This file is a clean-room restatement of the semantics visible at
+// the call sites (src/sim.cpp, src/level_gen.cpp).  All float code here must be compiled
+// with -ffp-contract=off: the HIP product evaluates the same expression trees in the same
+// order so results agree bit for bit.
+#pragma once
+#include <cstdint>
+#include <cmath>
+
+namespace hsref {
+
+struct V3 { float x, y, z; };
+struct V2 { float x, y; };
+struct Q  { float w, x, y, z; };
+
+static inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+static inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+static inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static inline V3 operator*(float s, V3 a) { return {a.x * s, a.y * s, a.z * s}; }
+static inline V3 mulc(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+static inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+static inline float len2(V3 a) { return dot(a, a); }
+static inline float len(V3 a) { return sqrtf(dot(a, a)); }
+// (madrona Vector3::normalize, used at sim.cpp:591,733,786) — v * (1/len)
+static inline V3 normalize(V3 a) { float inv = 1.f / len(a); return a * inv; }
+static inline float getc(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// ---- quaternions (w,x,y,z), madrona::math::Quat call sites sim.cpp:225,350,408-409,469 ----
+static inline Q qmul(Q a, Q b) {
+    return {
+        (a.w * b.w - a.x * b.x) - (a.y * b.y + a.z * b.z),
+        (a.w * b.x + a.x * b.w) + (a.y * b.z - a.z * b.y),
+        (a.w * b.y - a.x * b.z) + (a.y * b.w + a.z * b.x),
+        (a.w * b.z + a.x * b.y) - (a.y * b.x - a.z * b.w),
+    };
+}
+static inline Q qinv(Q q) { return {q.w, -q.x, -q.y, -q.z}; }  // unit quaternions: conjugate
+static inline Q qnormalize(Q q) {
+    float n2 = (q.w * q.w + q.x * q.x) + (q.y * q.y + q.z * q.z);
+    float inv = 1.f / sqrtf(n2);
+    return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+// v' = 2(p.v)p + (2w^2-1)v + 2w(p x v)
+static inline V3 qrot(Q q, V3 v) {
+    V3 p = {q.x, q.y, q.z};
+    float s = q.w;
+    float d2 = 2.f * dot(p, v);
+    float k = 2.f * s * s - 1.f;
+    V3 c = cross(p, v);
+    float s2 = 2.f * s;
+    return {(d2 * p.x + k * v.x) + s2 * c.x, (d2 * p.y + k * v.y) + s2 * c.y,
+            (d2 * p.z + k * v.z) + s2 * c.z};
+}
+
+// ---- deterministic transcendental functions (shared formulas with the HIP product) ----
+// sin/cos: Cody-Waite reduction by pi/2 + cephes single-precision minimax polynomials.
+static inline void hs_sincosf(float x, float *s_out, float *c_out) {
+    const float two_over_pi = 0.63661977236758134308f;
+    const float pio2_hi = 1.5707962512969970703125f;     // pi/2 split: hi + lo
+    const float pio2_lo = 7.54978995489188216e-8f;
+    float kf = x * two_over_pi;
+    int k = (int)(kf + (kf >= 0.f ? 0.5f : -0.5f));
+    float fk = (float)k;
+    float r = (x - fk * pio2_hi) - fk * pio2_lo;
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.f;
+    float s, c;
+    switch (k & 3) {
+    case 0: s = sp; c = cp; break;
+    case 1: s = cp; c = -sp; break;
+    case 2: s = -sp; c = -cp; break;
+    default: s = -cp; c = sp; break;
+    }
+    *s_out = s; *c_out = c;
+}
+
+static inline float hs_atanf(float xin) {
+    float sign = xin < 0.f ? -1.f : 1.f;
+    float x = fabsf(xin);
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.f) / (x + 1.f); }
+    else { y = 0.f; }
+    float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z
+              - 3.33329491539e-1f) * z * x + x);
+    return sign * y;
+}
+
+static inline float hs_atan2f(float y, float x) {
+    const float pi = 3.14159265358979323846f;
+    if (x == 0.f) {
+        if (y > 0.f) return 0.5f * pi;
+        if (y < 0.f) return -0.5f * pi;
+        return 0.f;
+    }
+    float a = hs_atanf(y / x);
+    if (x < 0.f) { a = (y >= 0.f) ? a + pi : a - pi; }
+    return a;
+}
+
+static inline float hs_asinf(float xin) {
+    float sign = xin < 0.f ? -1.f : 1.f;
+    float a = fabsf(xin);
+    float z, x;
+    bool flag = a > 0.5f;
+    if (flag) { z = 0.5f * (1.f - a); x = sqrtf(z); }
+    else { x = a; z = x * x; }
+    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z
+                + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+    if (flag) { p = p + p; p = 1.5707963267948966f - p; }
+    return sign * p;
+}
+
+// Quat::angleAxis(angle, {0,0,1}) (level_gen.cpp:139,179,215,277)
+static inline Q quat_angle_axis_z(float angle) {
+    float s, c;
+    hs_sincosf(angle * 0.5f, &s, &c);
+    return {c, 0.f, 0.f, s};
+}
+
+// ---- 3x3 rotation (columns) from a unit quaternion ----
+struct M3 { V3 c0, c1, c2; };
+static inline M3 m3_from_quat(Q q) {
+    float x2 = q.x * q.x, y2 = q.y * q.y, z2 = q.z * q.z;
+    float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+    float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    M3 m;
+    m.c0 = {1.f - 2.f * (y2 + z2), 2.f * (xy + wz), 2.f * (xz - wy)};
+    m.c1 = {2.f * (xy - wz), 1.f - 2.f * (x2 + z2), 2.f * (yz + wx)};
+    m.c2 = {2.f * (xz + wy), 2.f * (yz - wx), 1.f - 2.f * (x2 + y2)};
+    return m;
+}
+
+// ---- AABB (madrona::math::AABB call sites level_gen.cpp:104-121,142-143) ----
+struct AABB { V3 lo, hi; };
+
+// Real-Time Collision Detection 4.2.6 style transformed AABB: M = R * diag(scale).
+static inline AABB aabb_apply_trs(AABB b, V3 t, Q r, V3 s) {
+    M3 m = m3_from_quat(r);
+    m.c0 = m.c0 * s.x; m.c1 = m.c1 * s.y; m.c2 = m.c2 * s.z;
+    float lo[3] = {t.x, t.y, t.z}, hi[3] = {t.x, t.y, t.z};
+    const V3 cols[3] = {m.c0, m.c1, m.c2};
+    const float bl[3] = {b.lo.x, b.lo.y, b.lo.z}, bh[3] = {b.hi.x, b.hi.y, b.hi.z};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            float mij = getc(cols[j], i);
+            float e = mij * bl[j], f = mij * bh[j];
+            if (e < f) { lo[i] += e; hi[i] += f; } else { lo[i] += f; hi[i] += e; }
+        }
+    }
+    return {{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+}
+static inline bool aabb_overlaps(const AABB &a, const AABB &b) {
+    return a.lo.x < b.hi.x && b.lo.x < a.hi.x && a.lo.y < b.hi.y && b.lo.y < a.hi.y &&
+           a.lo.z < b.hi.z && b.lo.z < a.hi.z;
+}
+
+}  // namespace hsref
