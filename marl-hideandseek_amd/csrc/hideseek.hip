@@ -1,0 +1,316 @@
+// libhideseek.so — host side of the C ABI declared in include/hideseek.h.
+// Owns the HBM allocations, launches the three kernels of a step on one HIP stream and
+// hands out non-owning tensor descriptors (replaces Manager::Impl, src/mgr.cpp:86-437, 674-822).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hideseek.h"
+#include "hs_state.h"
+#include "hs_k_reset.h"
+#include "hs_k_observe.h"
+#include "hs_k_physics.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HS_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(HS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+}  // namespace
+
+struct hs_sim {
+    hs_config cfg;
+    hs::SimState S;
+    int A;
+    std::vector<void *> allocs;
+    hs_tensor_desc exports[HS_NUM_EXPORTS];
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_ms[3] = {0.f, 0.f, 0.f};
+    bool initialised = false;
+
+    template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
+        void *d = nullptr;
+        HS_HIP(hipMalloc(&d, n * sizeof(T) > 0 ? n * sizeof(T) : 4));
+        HS_HIP(hipMemset(d, fill_byte, n * sizeof(T) > 0 ? n * sizeof(T) : 4));
+        allocs.push_back(d);
+        *p = (T *)d;
+        return HS_OK;
+    }
+};
+
+namespace {
+
+void set_desc(hs_sim *s, int id, void *ptr, int dtype, std::initializer_list<int64_t> dims) {
+    hs_tensor_desc &d = s->exports[id];
+    d.ptr = ptr; d.dtype = dtype; d.ndim = (int32_t)dims.size(); d.gpu_id = s->cfg.gpu_id;
+    int i = 0;
+    for (int64_t v : dims) d.dims[i++] = v;
+    for (; i < 4; ++i) d.dims[i] = 1;
+}
+
+int launch_step(hs_sim *s, hipStream_t strm, bool first) {
+    const hs::SimState &S = s->S;
+    const int N = S.N;
+    const bool prof = s->profiling;
+    if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
+    if (!first) {
+        if (s->A <= 5) {
+            hipLaunchKernelGGL(hs::k_physics<16>, dim3((N + 3) / 4), dim3(64), 0, strm, S);
+        } else {
+            hipLaunchKernelGGL(hs::k_physics<32>, dim3((N + 1) / 2), dim3(64), 0, strm, S);
+        }
+    }
+    if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
+    hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
+    if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
+    if (!(S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS))
+        hipLaunchKernelGGL(hs::k_observe, dim3(N), dim3(256), 0, strm, S);
+    if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hs_last_error(void) { return g_err.c_str(); }
+const char *hs_version(void) { return "hideseek-mi355x 0.1 (gfx950)"; }
+
+int32_t hs_create(const hs_config *cfg, hs_sim **out) {
+    if (!cfg || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->exec_mode != HS_EXEC_GPU)
+        return fail(HS_ERR_UNSUPPORTED,
+                    "exec_mode CPU is not provided by libhideseek: the HIP path is the only execution path");
+    const int A = cfg->max_hiders + cfg->max_seekers;
+    if (cfg->num_worlds <= 0) return fail(HS_ERR_INVALID_ARG, "num_worlds must be > 0");
+    if (A <= 0 || A > hs::kMaxAgents || cfg->max_hiders > 3 || cfg->max_seekers > 3 || cfg->min_hiders < 0 ||
+        cfg->min_seekers < 0 || cfg->min_hiders > cfg->max_hiders || cfg->min_seekers > cfg->max_seekers)
+        return fail(HS_ERR_INVALID_ARG, "hider/seeker counts out of range (<= 3 each, src/sim.hpp:338-341)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(HS_ERR_NO_DEVICE, "no HIP device visible: libhideseek has no CPU fallback");
+    if (cfg->gpu_id < 0 || cfg->gpu_id >= ndev) return fail(HS_ERR_INVALID_ARG, "gpu_id out of range");
+    HS_HIP(hipSetDevice(cfg->gpu_id));
+
+    hs_sim *s = new hs_sim();
+    s->cfg = *cfg;
+    s->A = A;
+    hs::SimState &S = s->S;
+    std::memset(&S, 0, sizeof(S));
+    const size_t N = (size_t)cfg->num_worlds, R = N * (size_t)A;
+    S.N = (int)N; S.A = A; S.flags = cfg->sim_flags;
+    S.initKey = {cfg->rand_seed, 0u};          // rand::initKey (mgr.cpp:678)
+    S.minHiders = cfg->min_hiders; S.maxHiders = cfg->max_hiders;
+    S.minSeekers = cfg->min_seekers; S.maxSeekers = cfg->max_seekers;
+    S.worldOffset = cfg->world_offset;
+    const int D = hs::kNumDSlots, AG = hs::kMaxAgents;
+    int rc = HS_OK;
+#define HS_ALLOC(ptr, n) if ((rc = s->dalloc(&(ptr), (n))) != HS_OK) { hs_destroy(s); return rc; }
+    HS_ALLOC(S.bpos, 3 * D * N); HS_ALLOC(S.brot, 4 * D * N); HS_ALLOC(S.blin, 3 * D * N);
+    HS_ALLOC(S.bang, 3 * D * N); HS_ALLOC(S.bmeta, D * N); HS_ALLOC(S.aforce, 4 * AG * N);
+    HS_ALLOC(S.walls, 4 * hs::kMaxWalls * N); HS_ALLOC(S.planes, 4 * hs::kMaxPlanes * N);
+    HS_ALLOC(S.numWalls, N); HS_ALLOC(S.numPlanes, N);
+    HS_ALLOC(S.curWorldEpisode, N); HS_ALLOC(S.rngKeyA, N); HS_ALLOC(S.rngKeyB, N); HS_ALLOC(S.rngCount, N);
+    HS_ALLOC(S.curEpisodeStep, N); HS_ALLOC(S.hiderTeamReward, N); HS_ALLOC(S.counts, N); HS_ALLOC(S.teams, N);
+    HS_ALLOC(S.runningScores, 2 * N); HS_ALLOC(S.grabOther, AG * N); HS_ALLOC(S.grabData, 8 * AG * N);
+    HS_ALLOC(S.xReset, N); HS_ALLOC(S.xPrep, R); HS_ALLOC(S.xAction, R * 5); HS_ALLOC(S.xSelfType, R);
+    HS_ALLOC(S.xSeed, R * 2); HS_ALLOC(S.xDone, R); HS_ALLOC(S.xPolicy, R);
+    HS_ALLOC(S.xSelfObs, R * 13); HS_ALLOC(S.xSelfMask, R); HS_ALLOC(S.xAgentObs, R * 5 * 14);
+    HS_ALLOC(S.xBoxObs, R * 9 * 17); HS_ALLOC(S.xRampObs, R * 2 * 14); HS_ALLOC(S.xVisAgents, R * 5);
+    HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
+    HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
+#undef HS_ALLOC
+    // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
+    {
+        std::vector<int32_t> ones(N, 1), neg(AG * N, -1);
+        if (hipMemcpy(S.xReset, ones.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(S.grabOther, neg.data(), AG * N * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hs_destroy(s);
+            return fail(HS_ERR_HIP, "initial upload failed");
+        }
+    }
+    for (auto &e : s->ev) {
+        if (hipEventCreate(&e) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipEventCreate failed"); }
+    }
+    std::memset(s->exports, 0, sizeof(s->exports));
+    const int64_t n = (int64_t)N, r = (int64_t)R;
+    set_desc(s, HS_EXPORT_RESET, S.xReset, HS_DTYPE_I32, {n, 1});
+    set_desc(s, HS_EXPORT_PREP_COUNTER, S.xPrep, HS_DTYPE_I32, {r, 1});
+    set_desc(s, HS_EXPORT_ACTION, S.xAction, HS_DTYPE_I32, {r, 5});
+    set_desc(s, HS_EXPORT_SELF_OBS, S.xSelfObs, HS_DTYPE_F32, {r, 13});
+    set_desc(s, HS_EXPORT_SELF_TYPE, S.xSelfType, HS_DTYPE_I32, {r, 1});
+    set_desc(s, HS_EXPORT_SELF_MASK, S.xSelfMask, HS_DTYPE_F32, {r, 1});
+    set_desc(s, HS_EXPORT_AGENT_OBS, S.xAgentObs, HS_DTYPE_F32, {r, 5, 14});
+    set_desc(s, HS_EXPORT_BOX_OBS, S.xBoxObs, HS_DTYPE_F32, {r, 9, 17});
+    set_desc(s, HS_EXPORT_RAMP_OBS, S.xRampObs, HS_DTYPE_F32, {r, 2, 14});
+    set_desc(s, HS_EXPORT_AGENT_VIS_MASKS, S.xVisAgents, HS_DTYPE_F32, {r, 5, 1});
+    set_desc(s, HS_EXPORT_BOX_VIS_MASKS, S.xVisBoxes, HS_DTYPE_F32, {r, 9, 1});
+    set_desc(s, HS_EXPORT_RAMP_VIS_MASKS, S.xVisRamps, HS_DTYPE_F32, {r, 2, 1});
+    set_desc(s, HS_EXPORT_LIDAR, S.xLidar, HS_DTYPE_F32, {r, 30});
+    set_desc(s, HS_EXPORT_SEED, S.xSeed, HS_DTYPE_I32, {r, 2});
+    set_desc(s, HS_EXPORT_REWARD, S.xReward, HS_DTYPE_F32, {r, 1});
+    set_desc(s, HS_EXPORT_DONE, S.xDone, HS_DTYPE_I32, {r, 1});
+    set_desc(s, HS_EXPORT_GLOBAL_DEBUG_POSITIONS, S.xGlobalPos, HS_DTYPE_F32, {n, 17, 2});
+    set_desc(s, HS_EXPORT_AGENT_POLICY, S.xPolicy, HS_DTYPE_I32, {r, 1});
+    set_desc(s, HS_EXPORT_EPISODE_RESULT, S.xEpisodeResult, HS_DTYPE_F32, {n, 2});
+    *out = s;
+    return HS_OK;
+}
+
+void hs_destroy(hs_sim *s) {
+    if (!s) return;
+    hipDeviceSynchronize();
+    for (void *p : s->allocs) hipFree(p);
+    for (auto &e : s->ev) if (e) hipEventDestroy(e);
+    delete s;
+}
+
+int32_t hs_agents_per_world(const hs_sim *s) { return s ? s->A : 0; }
+
+int32_t hs_init(hs_sim *s) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = launch_step(s, nullptr, true);
+    if (rc != HS_OK) return rc;
+    HS_HIP(hipStreamSynchronize(nullptr));
+    s->initialised = true;
+    return HS_OK;
+}
+
+int32_t hs_step(hs_sim *s) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = launch_step(s, nullptr, false);
+    if (rc != HS_OK) return rc;
+    HS_HIP(hipStreamSynchronize(nullptr));
+    if (s->profiling)
+        for (int i = 0; i < 3; ++i) HS_HIP(hipEventElapsedTime(&s->last_ms[i], s->ev[i], s->ev[i + 1]));
+    return HS_OK;
+}
+
+int32_t hs_step_async(hs_sim *s, void *hip_stream) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    return launch_step(s, (hipStream_t)hip_stream, false);
+}
+
+int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
+    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    if (id < 0 || id >= HS_NUM_EXPORTS) return fail(HS_ERR_INVALID_ARG, "export id out of range");
+    if (!s->exports[id].ptr) {
+        // renderer / checkpoint outputs are allocated on first request and never written
+        HS_HIP(hipSetDevice(s->cfg.gpu_id));
+        const int64_t n = s->S.N, r = (int64_t)s->S.N * s->A;
+        const int64_t H = s->cfg.batch_render_height > 0 ? s->cfg.batch_render_height : 64;
+        const int64_t Wd = s->cfg.batch_render_width > 0 ? s->cfg.batch_render_width : 64;
+        int rc;
+        if (id == HS_EXPORT_RGB) {
+            uint8_t *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd * 4))) != HS_OK) return rc;
+            set_desc(s, id, p, HS_DTYPE_U8, {r, H, Wd, 4});
+        } else if (id == HS_EXPORT_DEPTH) {
+            float *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd))) != HS_OK) return rc;
+            set_desc(s, id, p, HS_DTYPE_F32, {r, H, Wd, 1});
+        } else if (id == HS_EXPORT_CHECKPOINT_CONTROL) {
+            int32_t *p; if ((rc = s->dalloc(&p, (size_t)n)) != HS_OK) return rc;
+            set_desc(s, id, p, HS_DTYPE_I32, {n, 1});
+        } else if (id == HS_EXPORT_CHECKPOINT) {
+            uint8_t *p; if ((rc = s->dalloc(&p, (size_t)(n * 1392))) != HS_OK) return rc;
+            set_desc(s, id, p, HS_DTYPE_U8, {n, 1392});
+        } else {
+            return fail(HS_ERR_INVALID_ARG, "export not available");
+        }
+    }
+    *out = s->exports[id];
+    return HS_OK;
+}
+
+int32_t hs_trigger_reset(hs_sim *s, int32_t world, int32_t level) {
+    if (!s || world < 0 || world >= s->S.N) return fail(HS_ERR_INVALID_ARG, "world index out of range");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipMemcpy(s->S.xReset + world, &level, sizeof(int32_t), hipMemcpyHostToDevice));
+    return HS_OK;
+}
+
+int32_t hs_set_action(hs_sim *s, int32_t agent, int32_t x, int32_t y, int32_t r, int32_t g, int32_t l) {
+    if (!s || agent < 0 || agent >= s->S.N * s->A) return fail(HS_ERR_INVALID_ARG, "agent index out of range");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int32_t a[5] = {x, y, r, g ? 1 : 0, l ? 1 : 0};
+    HS_HIP(hipMemcpy(s->S.xAction + (size_t)agent * 5, a, sizeof(a), hipMemcpyHostToDevice));
+    return HS_OK;
+}
+
+int32_t hs_debug_dump_bodies(hs_sim *s, float *bodies, int32_t *meta) {
+    if (!s || !bodies || !meta) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    const size_t N = s->S.N, D = hs::kNumDSlots;
+    std::vector<float> pos(3 * D * N), rot(4 * D * N), lin(3 * D * N), ang(3 * D * N);
+    std::vector<int32_t> m(D * N);
+    HS_HIP(hipMemcpy(pos.data(), s->S.bpos, pos.size() * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(rot.data(), s->S.brot, rot.size() * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(lin.data(), s->S.blin, lin.size() * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(ang.data(), s->S.bang, ang.size() * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(m.data(), s->S.bmeta, m.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < N; ++w)
+        for (size_t i = 0; i < D; ++i) {
+            float *o = bodies + (w * D + i) * 13;
+            for (size_t c = 0; c < 3; ++c) {
+                o[c] = pos[(c * D + i) * N + w]; o[7 + c] = lin[(c * D + i) * N + w]; o[10 + c] = ang[(c * D + i) * N + w];
+            }
+            for (size_t c = 0; c < 4; ++c) o[3 + c] = rot[(c * D + i) * N + w];
+            int32_t mm = m[i * N + w];
+            int32_t *om = meta + (w * D + i) * 3;
+            if (mm == 0) { om[0] = -1; om[1] = 2; om[2] = 0; }
+            else { om[0] = (mm & 0xff) - 1; om[1] = (mm >> 8) & 0xff; om[2] = (mm >> 16) & 0xff; }
+        }
+    return HS_OK;
+}
+
+int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
+    if (!s || !walls || !info) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    const size_t N = s->S.N, K = hs::kMaxWalls;
+    std::vector<float> wl(4 * K * N);
+    std::vector<int32_t> nw(N), np(N), cnt(N), step(N);
+    HS_HIP(hipMemcpy(wl.data(), s->S.walls, wl.size() * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(nw.data(), s->S.numWalls, N * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(np.data(), s->S.numPlanes, N * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(cnt.data(), s->S.counts, N * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(step.data(), s->S.curEpisodeStep, N * 4, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < N; ++w) {
+        for (size_t k = 0; k < K; ++k)
+            for (size_t c = 0; c < 4; ++c)
+                walls[(w * K + k) * 4 + c] = (int)k < nw[w] ? wl[(c * K + k) * N + w] : 0.f;
+        int32_t *m = info + w * 8;
+        const int c = cnt[w];
+        m[0] = nw[w]; m[1] = np[w]; m[2] = (c >> 12) & 15; m[3] = (c >> 16) & 15; m[4] = c & 15; m[5] = (c >> 4) & 15;
+        m[6] = step[w]; m[7] = (c >> 20) & 1;
+    }
+    return HS_OK;
+}
+
+int32_t hs_set_profiling(hs_sim *s, int32_t enabled) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    s->profiling = enabled != 0;
+    return HS_OK;
+}
+
+int32_t hs_last_step_kernel_ms(hs_sim *s, float out_ms[3]) {
+    if (!s || !out_ms) return fail(HS_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < 3; ++i) out_ms[i] = s->last_ms[i];
+    return HS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,678 @@
+// Physics + game-logic kernel: everything between the start of Manager::step and the reset node
+// of the Step task graph (src/sim.cpp:1140-1201):
+//   movementSystem | instantMovementSystem  (:202-254)
+//   [broadphase]  actionSystem               (:270-370)
+//   4 XPBD substeps (PhysicsSystem::setupPhysicsStepTasks, :1162-1163)
+//   agentZeroVelSystem (:258-268), rewardsVisSystem (:763-804),
+//   outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893)
+//
+// Mapping: one GROUP of G lanes per world (G = 16 for <= 5 agents, 32 for 6), 64/G worlds per
+// wave, one wave per workgroup.  Lane l of a group owns movable-body slot l.  The world's
+// poses, velocities, static geometry, contact manifolds and joints stay in LDS for the whole
+// step (4 substeps), so HBM sees each body column once in and once out per step.
+// Candidate pairs are found by all-pairs AABB tests (<= 17 bodies, <= 36 walls: no BVH build),
+// compacted in pair order with a per-group prefix sum, and the convex tests are then spread
+// over the lanes of the group.  The Gauss-Seidel order is the oracle's: joints, body-body
+// manifolds in pair order (lane 0), then every body's static manifolds (one lane per body).
+#pragma once
+#include "hs_state.h"
+#include "hs_rays.h"
+#include "hs_collide.h"
+
+namespace hs {
+
+struct ManDD { int a, b, np; float muS, muD; float n[3]; float rA[4][3]; float rB[4][3]; float lam[4]; };
+struct ManS { int np; float muS, muD; float n[3]; float rA[4][3]; float offB[4]; float lam[4]; };
+
+struct PhysWorld {
+    WorldGeom g;
+    float lin[kNumDSlots][3], ang[kNumDSlots][3];
+    float ppos[kNumDSlots][3], prot[kNumDSlots][4];
+    float lo[kNumDSlots][3], hi[kNumDSlots][3];
+    float hv[kNumDSlots][8][3];
+    int cnt[32];
+    int ndd, nsc;
+    unsigned char ddA[kMaxDDCand], ddB[kMaxDDCand], scBody[kMaxSCand], scStatic[kMaxSCand];
+    ManDD dd[kMaxDDCand];
+    ManS sc[kMaxSCand];
+    int grabOther[kMaxAgents];
+    float grabData[kMaxAgents][8];
+    float aforce[kMaxAgents][4];
+    int actGL[kMaxAgents];
+    int counts, teams, step;
+    float hiderReward;
+};
+
+struct BodyS { V3 pos; Q rot; V3 ppos; Q prot; V3 lin, ang; float invM; V3 invI; };
+
+HSD V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+HSD Q ld4(const float *p) { return {p[0], p[1], p[2], p[3]}; }
+HSD void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+HSD void st4(float *p, Q q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+
+HSD void body_load(const PhysWorld &pw, int s, BodyS &b) {
+    b.pos = ld3(pw.g.pos[s]); b.rot = ld4(pw.g.rot[s]);
+    b.ppos = ld3(pw.ppos[s]); b.prot = ld4(pw.prot[s]);
+    b.lin = ld3(pw.lin[s]); b.ang = ld3(pw.ang[s]);
+    const int m = pw.g.meta[s];
+    const bool dyn = m != 0 && meta_resp(m) == RESP_DYNAMIC;
+    b.invM = dyn ? obj_inv_mass(meta_obj(m)) : 0.f;
+    b.invI = dyn ? obj_inv_inertia(meta_obj(m)) : V3{0.f, 0.f, 0.f};
+}
+HSD void body_store_pose(PhysWorld &pw, int s, const BodyS &b) { st3(pw.g.pos[s], b.pos); st4(pw.g.rot[s], b.rot); }
+HSD void body_store_vel(PhysWorld &pw, int s, const BodyS &b) { st3(pw.lin[s], b.lin); st3(pw.ang[s], b.ang); }
+
+HSD V3 apply_inv_inertia(Q q, V3 invI, V3 v) {
+    V3 l = qrot(qinv(q), v);
+    l = mulc(l, invI);
+    return qrot(q, l);
+}
+HSD float gen_inv_mass(Q q, float invM, V3 invI, V3 r, V3 n) {
+    V3 rn = cross(r, n);
+    V3 l = qrot(qinv(q), rn);
+    return invM + ((l.x * l.x * invI.x + l.y * l.y * invI.y) + l.z * l.z * invI.z);
+}
+HSD Q quat_add_rotation(Q q, V3 dth) {
+    Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
+    Q r = {q.w + 0.5f * dq.w, q.x + 0.5f * dq.x, q.y + 0.5f * dq.y, q.z + 0.5f * dq.z};
+    return qnormalize(r);
+}
+HSD bool has_mass(const BodyS &b) { return b.invM != 0.f || b.invI.z != 0.f || b.invI.x != 0.f || b.invI.y != 0.f; }
+
+template <bool HAS_B>
+HSD void apply_pos_impulse(BodyS &A, V3 rA, BodyS &B, V3 rB, V3 p) {
+    if (has_mass(A)) {
+        A.pos = A.pos - p * A.invM;
+        V3 dth = apply_inv_inertia(A.rot, A.invI, cross(rA, p));
+        A.rot = quat_add_rotation(A.rot, -dth);
+    }
+    if (HAS_B && has_mass(B)) {
+        B.pos = B.pos + p * B.invM;
+        V3 dth = apply_inv_inertia(B.rot, B.invI, cross(rB, p));
+        B.rot = quat_add_rotation(B.rot, dth);
+    }
+}
+
+// One contact point of the XPBD position pass (normal + static friction).  Returns the normal
+// multiplier added this pass.
+template <bool HAS_B>
+HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float offB, float muS) {
+    V3 rAw = qrot(A.rot, rAl);
+    V3 pA = A.pos + rAw;
+    V3 rBw = HAS_B ? qrot(B.rot, rBl) : V3{0.f, 0.f, 0.f};
+    V3 pB = HAS_B ? B.pos + rBw : V3{0.f, 0.f, 0.f};
+    float d = HAS_B ? dot(pA - pB, n) : dot(pA, n) - offB;
+    if (!(d > 0.f)) return 0.f;
+    V3 pAprev = A.ppos + qrot(A.prot, rAl);
+    V3 pBprev = HAS_B ? B.ppos + qrot(B.prot, rBl) : V3{0.f, 0.f, 0.f};
+    float dprev = HAS_B ? dot(pAprev - pBprev, n) : dot(pAprev, n) - offB;
+    float excess = dprev - kMaxDepenVel * kSubstepH;
+    if (excess > 0.f) d = d - excess;
+    if (!(d > 0.f)) return 0.f;
+    float wA = gen_inv_mass(A.rot, A.invM, A.invI, rAw, n);
+    float wB = HAS_B ? gen_inv_mass(B.rot, B.invM, B.invI, rBw, n) : 0.f;
+    float wsum = wA + wB;
+    if (!(wsum > 0.f)) return 0.f;
+    float lam = d / wsum;
+    apply_pos_impulse<HAS_B>(A, rAw, B, rBw, n * lam);
+    rAw = qrot(A.rot, rAl);
+    pA = A.pos + rAw;
+    V3 dp;
+    if (HAS_B) {
+        rBw = qrot(B.rot, rBl);
+        pB = B.pos + rBw;
+        dp = (pA - pAprev) - (pB - pBprev);
+    } else {
+        dp = pA - pAprev;
+    }
+    V3 dpt = dp - n * dot(dp, n);
+    float lt2 = len2(dpt);
+    if (lt2 > 1e-12f) {
+        float lt = sqrtf(lt2);
+        V3 t = dpt * (1.f / lt);
+        float wtA = gen_inv_mass(A.rot, A.invM, A.invI, rAw, t);
+        float wtB = HAS_B ? gen_inv_mass(B.rot, B.invM, B.invI, rBw, t) : 0.f;
+        float wts = wtA + wtB;
+        if (wts > 0.f) {
+            float lamT = lt / wts;
+            if (lamT < muS * lam) apply_pos_impulse<HAS_B>(A, rAw, B, rBw, t * lamT);
+        }
+    }
+    return lam;
+}
+
+// One contact point of the velocity pass (dynamic friction, restitution 0).
+template <bool HAS_B>
+HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float lamN, float muD) {
+    const float h = kSubstepH;
+    if (!(lamN > 0.f)) return;
+    V3 rAw = qrot(A.rot, rAl);
+    V3 rBw = HAS_B ? qrot(B.rot, rBl) : V3{0.f, 0.f, 0.f};
+    V3 v = {0.f, 0.f, 0.f};
+    if (A.invM + A.invI.x + A.invI.y + A.invI.z != 0.f) v = A.lin + cross(A.ang, rAw);
+    if (HAS_B && B.invM + B.invI.x + B.invI.y + B.invI.z != 0.f) v = v - (B.lin + cross(B.ang, rBw));
+    float vn = dot(n, v);
+    V3 vt = v - n * vn;
+    float vtl = len(vt);
+    V3 dv = -(n * vn);
+    if (vtl > 1e-9f) {
+        float fn = lamN / (h * h);
+        float mag = fminf(h * muD * fn, vtl);
+        dv = dv - vt * (mag / vtl);
+    }
+    float dvl = len(dv);
+    if (!(dvl > 1e-9f)) return;
+    V3 dir = dv * (1.f / dvl);
+    float wA = gen_inv_mass(A.rot, A.invM, A.invI, rAw, dir);
+    float wB = HAS_B ? gen_inv_mass(B.rot, B.invM, B.invI, rBw, dir) : 0.f;
+    float ws = wA + wB;
+    if (!(ws > 0.f)) return;
+    V3 p = dir * (dvl / ws);
+    A.lin = A.lin + p * A.invM;
+    A.ang = A.ang + apply_inv_inertia(A.rot, A.invI, cross(rAw, p));
+    if (HAS_B) {
+        B.lin = B.lin - p * B.invM;
+        B.ang = B.ang - apply_inv_inertia(B.rot, B.invI, cross(rBw, p));
+    }
+}
+
+// Fixed grab joint (sim.cpp:343-356): angular alignment, then anchor coincidence.
+HSD void solve_grab_joint(PhysWorld &pw, int agent) {
+    const int other = pw.grabOther[agent];
+    if (other < 0) return;
+    const int sa = kAgentSlot0 + agent;
+    BodyS A, B;
+    body_load(pw, sa, A); body_load(pw, other, B);
+    const float *gd = pw.grabData[agent];
+    const V3 r2 = {gd[0], gd[1], gd[2]};
+    const Q attach2 = {gd[3], gd[4], gd[5], gd[6]};
+    const float sep = gd[7];
+    {
+        Q qa = qmul(A.rot, Q{1.f, 0.f, 0.f, 0.f}), qb = qmul(B.rot, attach2);
+        Q dq = qmul(qa, qinv(qb));
+        V3 dphi = {2.f * dq.x, 2.f * dq.y, 2.f * dq.z};
+        if (dq.w < 0.f) dphi = -dphi;
+        float th2 = len2(dphi);
+        if (th2 > 1e-12f) {
+            float th = sqrtf(th2);
+            V3 ax = dphi * (1.f / th);
+            V3 la = qrot(qinv(A.rot), ax), lb = qrot(qinv(B.rot), ax);
+            float wA = (la.x * la.x * A.invI.x + la.y * la.y * A.invI.y) + la.z * la.z * A.invI.z;
+            float wB = (lb.x * lb.x * B.invI.x + lb.y * lb.y * B.invI.y) + lb.z * lb.z * B.invI.z;
+            float ws = wA + wB;
+            if (ws > 0.f) {
+                V3 p = ax * (th / ws);
+                A.rot = quat_add_rotation(A.rot, -apply_inv_inertia(A.rot, A.invI, p));
+                B.rot = quat_add_rotation(B.rot, apply_inv_inertia(B.rot, B.invI, p));
+            }
+        }
+    }
+    {
+        V3 anchorA = V3{0.f, 1.25f, 0.5f} + V3{0.f, sep, 0.f};
+        V3 rAw = qrot(A.rot, anchorA), rBw = qrot(B.rot, r2);
+        V3 dx = (A.pos + rAw) - (B.pos + rBw);
+        float c2 = len2(dx);
+        if (c2 > 1e-12f) {
+            float c = sqrtf(c2);
+            V3 n = dx * (1.f / c);
+            float ws = gen_inv_mass(A.rot, A.invM, A.invI, rAw, n) + gen_inv_mass(B.rot, B.invM, B.invI, rBw, n);
+            if (ws > 0.f) apply_pos_impulse<true>(A, rAw, B, rBw, n * (c / ws));
+        }
+    }
+    body_store_pose(pw, sa, A); body_store_pose(pw, other, B);
+}
+
+// actionSystem for one world, agents in interface order (executed by lane 0 of the group).
+HSD void action_system(PhysWorld &pw, int A_) {
+    for (int i = 0; i < A_; ++i) {
+        const int fl = pw.actGL[i];
+        if (fl == 0) continue;
+        const int type = team_agent_type(pw.teams, i);
+        const int slot = kAgentSlot0 + i;
+        const V3 mpos = geom_pos(pw.g, slot);
+        const Q mrot = geom_rot(pw.g, slot);
+        if (fl & 2) {   // lock
+            float t; V3 o = mpos + V3{0.f, 0.f, 0.5f};
+            int hit = trace_ray(pw.g, o, qrot(mrot, {0.f, 1.f, 0.f}), 2.5f, &t);
+            if (hit >= 0 && hit < kNumDSlots) {
+                const int m = pw.g.meta[hit];
+                const int obj = meta_obj(m), resp = meta_resp(m), owner = meta_owner(m);
+                if (resp == RESP_STATIC) {
+                    if ((type == AGENT_SEEKER && owner == OWNER_SEEKER) || (type == AGENT_HIDER && owner == OWNER_HIDER))
+                        pw.g.meta[hit] = meta_pack(obj, RESP_DYNAMIC, OWNER_NONE);
+                } else if (owner == OWNER_NONE) {
+                    pw.g.meta[hit] = meta_pack(obj, RESP_STATIC, type == AGENT_HIDER ? OWNER_HIDER : OWNER_SEEKER);
+                }
+            }
+        }
+        if (fl & 1) {   // grab
+            if (pw.grabOther[i] >= 0) {
+                pw.grabOther[i] = -1;
+            } else {
+                float t; V3 o = mpos + V3{0.f, 0.f, 0.5f};
+                V3 dir = qrot(mrot, {0.f, 1.f, 0.f});
+                int hit = trace_ray(pw.g, o, dir, 2.5f, &t);
+                if (hit >= 0 && hit < kNumDSlots) {
+                    const int m = pw.g.meta[hit];
+                    if (meta_owner(m) == OWNER_NONE && meta_resp(m) == RESP_DYNAMIC) {
+                        V3 hit_pos = o + dir * t;
+                        Q erot = geom_rot(pw.g, hit);
+                        V3 r2 = qrot(qinv(erot), hit_pos - geom_pos(pw.g, hit));
+                        Q at2 = qnormalize(qmul(qinv(erot), mrot));
+                        pw.grabOther[i] = hit;
+                        float *gd = pw.grabData[i];
+                        gd[0] = r2.x; gd[1] = r2.y; gd[2] = r2.z;
+                        gd[3] = at2.w; gd[4] = at2.x; gd[5] = at2.y; gd[6] = at2.z;
+                        gd[7] = t - 1.25f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int G>
+__global__ void __launch_bounds__(64) k_physics(SimState S) {
+    constexpr int W = 64 / G;
+    __shared__ PhysWorld sh[W];
+    const int lane = threadIdx.x;
+    const int grp = lane / G, l = lane % G;
+    const int w = blockIdx.x * W + grp;
+    const int N = S.N, A_ = S.A;
+    const bool wok = w < N;
+    PhysWorld &pw = sh[grp];
+    const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
+
+    // ---------------- stage the world into LDS ----------------
+    if (wok) {
+        for (int s = l; s < kNumDSlots; s += G) {
+            pw.g.meta[s] = S.bmeta[s * N + w];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pw.g.pos[s][c] = S.bpos[(c * kNumDSlots + s) * N + w];
+                pw.lin[s][c] = S.blin[(c * kNumDSlots + s) * N + w];
+                pw.ang[s][c] = S.bang[(c * kNumDSlots + s) * N + w];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.g.rot[s][c] = S.brot[(c * kNumDSlots + s) * N + w];
+        }
+        const int nw = S.numWalls[w], npl = S.numPlanes[w];
+        for (int k = l; k < nw; k += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.g.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
+        }
+        for (int p = l; p < npl; p += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.g.plane[p][c] = S.planes[(c * kMaxPlanes + p) * N + w];
+        }
+        for (int i = l; i < kMaxAgents; i += G) {
+            pw.grabOther[i] = S.grabOther[i * N + w];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) pw.grabData[i][c] = S.grabData[(c * kMaxAgents + i) * N + w];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.aforce[i][c] = S.aforce[(c * kMaxAgents + i) * N + w];
+            pw.actGL[i] = 0;
+        }
+        if (l == 0) {
+            pw.g.numWalls = nw; pw.g.numPlanes = npl;
+            pw.counts = S.counts[w]; pw.teams = S.teams[w]; pw.step = S.curEpisodeStep[w];
+            pw.hiderReward = S.hiderTeamReward[w];
+        }
+    }
+    __syncthreads();
+
+    const int slot = l;                       // movable-body slot owned by this lane
+    const bool has_slot = wok && slot < kNumDSlots;
+    const int agent = slot - kAgentSlot0;     // agent interface index when >= 0
+    const bool is_agent_lane = has_slot && agent >= 0 && agent < A_;
+    bool acts = false;                        // agent takes part in movement/action this step
+    int32_t *act_row = nullptr;
+    if (is_agent_lane) {
+        const bool active = team_agent_active(pw.teams, agent) != 0;
+        const int type = team_agent_type(pw.teams, agent);
+        acts = active && !(type == AGENT_SEEKER && pw.step < kNumPrepSteps - 1);
+        act_row = S.xAction + (w * A_ + agent) * 5;
+    }
+    // ---------------- movementSystem / instantMovementSystem (sim.cpp:202-254) ----------------
+    if (acts) {
+        const int ax = act_row[0], ay = act_row[1], ar = act_row[2], ag = act_row[3], al = act_row[4];
+        float fx, fy, tz;
+        if (instant) { fx = 400.f * (float)(ax - 2); fy = 400.f * (float)(ay - 2); tz = 120.f * (float)(ar - 2); }
+        else { fx = 12.f * (float)(ax - 5); fy = 12.f * (float)(ay - 5); tz = 3.f * (float)(ar - 5); }
+        V3 f = qrot(geom_rot(pw.g, slot), {fx, fy, 0.f});
+        pw.aforce[agent][0] = f.x; pw.aforce[agent][1] = f.y; pw.aforce[agent][2] = f.z; pw.aforce[agent][3] = tz;
+        pw.actGL[agent] = (ag == 1 ? 1 : 0) | (al == 1 ? 2 : 0);
+        // "consume" the action (sim.cpp:365-369)
+        act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;
+    }
+    __syncthreads();
+    // ---------------- actionSystem (sim.cpp:270-370): rare, serial per world ----------------
+    if (wok && l == 0) action_system(pw, A_);
+    __syncthreads();
+
+    // per-lane constants of the owned body
+    V3 force = {0.f, 0.f, 0.f}; float torque_z = 0.f;
+    if (is_agent_lane) { force = ld3(pw.aforce[agent]); torque_z = pw.aforce[agent][3]; }
+
+    // ground-plane manifold of the owned body lives in registers
+    int g_np = 0; int g_vi[4] = {0, 0, 0, 0}; float g_off[4], g_lam[4]; V3 g_n = {0.f, 0.f, -1.f};
+    float g_muS = 0.f, g_muD = 0.f;
+
+    for (int sub = 0; sub < 4; ++sub) {
+        const int meta = has_slot ? pw.g.meta[slot] : 0;
+        const int obj = meta_obj(meta);
+        const bool present = meta != 0;
+        const bool dynamic = present && meta_resp(meta) == RESP_DYNAMIC;
+        // ---------- P1: integrate, hull vertices, AABB ----------
+        if (has_slot) {
+            V3 pos = ld3(pw.g.pos[slot]); Q rot = ld4(pw.g.rot[slot]);
+            st3(pw.ppos[slot], pos); st4(pw.prot[slot], rot);
+            if (dynamic) {
+                const float h = kSubstepH;
+                V3 lin = ld3(pw.lin[slot]), ang = ld3(pw.ang[slot]);
+                const float invM = obj_inv_mass(obj);
+                const V3 invI = obj_inv_inertia(obj);
+                lin = lin + (force * invM + V3{0.f, 0.f, kGravityZ}) * h;
+                pos = pos + lin * h;
+                Q qi = qinv(rot);
+                V3 wl = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, torque_z});
+                V3 I = {invI.x > 0.f ? 1.f / invI.x : 0.f, invI.y > 0.f ? 1.f / invI.y : 0.f, invI.z > 0.f ? 1.f / invI.z : 0.f};
+                V3 Iw = mulc(I, wl);
+                wl = wl + mulc(invI, tl - cross(wl, Iw)) * h;
+                ang = qrot(rot, wl);
+                rot = quat_add_rotation(rot, ang * h);
+                st3(pw.g.pos[slot], pos); st4(pw.g.rot[slot], rot);
+                st3(pw.lin[slot], lin); st3(pw.ang[slot], ang);
+            }
+            if (present) {
+                V3 lo, hi;
+                hull_build(obj, pos, rot, pw.hv[slot], &lo, &hi);
+                st3(pw.lo[slot], lo); st3(pw.hi[slot], hi);
+            }
+        }
+        __syncthreads();
+        // ---------- P2: candidate pairs, compacted in pair order ----------
+        unsigned dd_mask = 0; unsigned long long s_mask = 0ull; int s_planes = 0;
+        if (has_slot && present) {
+            const V3 lo = ld3(pw.lo[slot]), hi = ld3(pw.hi[slot]);
+            for (int j = slot + 1; j < kNumDSlots; ++j) {
+                const int mj = pw.g.meta[j];
+                if (mj == 0) continue;
+                if (!dynamic && meta_resp(mj) != RESP_DYNAMIC) continue;
+                const V3 lj = ld3(pw.lo[j]), hj = ld3(pw.hi[j]);
+                if (lo.x <= hj.x && lj.x <= hi.x && lo.y <= hj.y && lj.y <= hi.y && lo.z <= hj.z && lj.z <= hi.z)
+                    dd_mask |= 1u << j;
+            }
+            if (dynamic) {
+                s_planes = pw.g.numPlanes > 1 ? pw.g.numPlanes - 1 : 0;
+                const int nw = pw.g.numWalls;
+                for (int k = 0; k < nw; ++k) {
+                    const float cx = pw.g.wall[k][0], cy = pw.g.wall[k][1], hx = pw.g.wall[k][2], hy = pw.g.wall[k][3];
+                    if (lo.x <= cx + hx && cx - hx <= hi.x && lo.y <= cy + hy && cy - hy <= hi.y && lo.z <= 2.5f && 0.f <= hi.z)
+                        s_mask |= 1ull << k;
+                }
+            }
+        }
+        const int my_dd = __popc(dd_mask), my_sc = s_planes + __popcll(s_mask);
+        if (wok) pw.cnt[l] = my_dd | (my_sc << 16);
+        __syncthreads();
+        if (wok) {
+            int off_dd = 0, off_sc = 0, tot_dd = 0, tot_sc = 0;
+            for (int k = 0; k < G; ++k) {
+                const int c = pw.cnt[k];
+                if (k < l) { off_dd += c & 0xffff; off_sc += c >> 16; }
+                tot_dd += c & 0xffff; tot_sc += c >> 16;
+            }
+            if (l == 0) { pw.ndd = tot_dd < kMaxDDCand ? tot_dd : kMaxDDCand; pw.nsc = tot_sc < kMaxSCand ? tot_sc : kMaxSCand; }
+            unsigned mm = dd_mask;
+            while (mm) {
+                const int j = __ffs(mm) - 1; mm &= mm - 1;
+                if (off_dd < kMaxDDCand) { pw.ddA[off_dd] = (unsigned char)slot; pw.ddB[off_dd] = (unsigned char)j; }
+                off_dd++;
+            }
+            for (int p = 1; p <= s_planes; ++p) {
+                if (off_sc < kMaxSCand) { pw.scBody[off_sc] = (unsigned char)slot; pw.scStatic[off_sc] = (unsigned char)(kMaxWalls + p); }
+                off_sc++;
+            }
+            unsigned long long sm = s_mask;
+            while (sm) {
+                const int k = __ffsll((long long)sm) - 1; sm &= sm - 1;
+                if (off_sc < kMaxSCand) { pw.scBody[off_sc] = (unsigned char)slot; pw.scStatic[off_sc] = (unsigned char)k; }
+                off_sc++;
+            }
+        }
+        __syncthreads();
+        // ---------- P3: narrowphase, spread over the lanes of the group ----------
+        g_np = 0;
+        if (has_slot && dynamic && pw.g.numPlanes >= 1) {
+            HullRef hb = hull_ref_body(obj, ld3(pw.g.pos[slot]), ld4(pw.g.rot[slot]), pw.hv[slot]);
+            RawManifold raw;
+            const V3 pn = ld3(pw.g.plane[0]);
+            if (collide_hull_plane(hb, pn, pw.g.plane[0][3], raw)) {
+                g_np = raw.np; g_n = raw.n;
+                g_muS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+                g_muD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { g_vi[j] = raw.vidx[j]; g_off[j] = dot(raw.pB[j], raw.n); g_lam[j] = 0.f; }
+            }
+        }
+        if (wok) {
+            const int ndd = pw.ndd, nsc = pw.nsc;
+            for (int k = l; k < ndd; k += G) {
+                const int a = pw.ddA[k], b = pw.ddB[k];
+                const int oa = meta_obj(pw.g.meta[a]), ob = meta_obj(pw.g.meta[b]);
+                const V3 pa = ld3(pw.g.pos[a]), pb = ld3(pw.g.pos[b]);
+                const Q qa = ld4(pw.g.rot[a]), qb = ld4(pw.g.rot[b]);
+                HullRef ha = hull_ref_body(oa, pa, qa, pw.hv[a]);
+                HullRef hb = hull_ref_body(ob, pb, qb, pw.hv[b]);
+                RawManifold raw;
+                ManDD &m = pw.dd[k];
+                m.np = 0;
+                if (collide_hulls(ha, hb, raw)) {
+                    m.a = a; m.b = b; m.np = raw.np;
+                    m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob));
+                    m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
+                    st3(m.n, raw.n);
+                    const Q qai = qinv(qa), qbi = qinv(qb);
+                    for (int j = 0; j < raw.np; ++j) {
+                        st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
+                        st3(m.rB[j], qrot(qbi, raw.pB[j] - pb));
+                        m.lam[j] = 0.f;
+                    }
+                }
+            }
+            for (int k = l; k < nsc; k += G) {
+                const int a = pw.scBody[k], st = pw.scStatic[k];
+                const int oa = meta_obj(pw.g.meta[a]);
+                const V3 pa = ld3(pw.g.pos[a]);
+                const Q qa = ld4(pw.g.rot[a]);
+                HullRef ha = hull_ref_body(oa, pa, qa, pw.hv[a]);
+                RawManifold raw;
+                ManS &m = pw.sc[k];
+                m.np = 0;
+                if (st >= kMaxWalls) {
+                    const float *pl = pw.g.plane[st - kMaxWalls];
+                    if (collide_hull_plane(ha, ld3(pl), pl[3], raw)) {
+                        m.np = raw.np; st3(m.n, raw.n);
+                        m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
+                        m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
+                        for (int j = 0; j < raw.np; ++j) {
+                            st3(m.rA[j], hull_local_vertex(oa, raw.vidx[j]));
+                            m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
+                        }
+                    }
+                } else {
+                    HullRef hw = hull_ref_wall(pw.g.wall[st][0], pw.g.wall[st][1], pw.g.wall[st][2], pw.g.wall[st][3]);
+                    if (collide_hulls(ha, hw, raw)) {
+                        m.np = raw.np; st3(m.n, raw.n);
+                        m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_WALL));
+                        m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_WALL));
+                        const Q qai = qinv(qa);
+                        for (int j = 0; j < raw.np; ++j) {
+                            st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
+                            m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---------- P4: position solve ----------
+        if (wok && l == 0) {
+            for (int a = 0; a < kMaxAgents; ++a)
+                if (team_agent_active(pw.teams, a)) solve_grab_joint(pw, a);
+            const int ndd = pw.ndd;
+            for (int k = 0; k < ndd; ++k) {
+                ManDD &m = pw.dd[k];
+                if (m.np <= 0) continue;
+                BodyS Ab, Bb;
+                body_load(pw, m.a, Ab); body_load(pw, m.b, Bb);
+                const V3 n = ld3(m.n);
+                for (int j = 0; j < m.np; ++j)
+                    m.lam[j] += solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+                body_store_pose(pw, m.a, Ab); body_store_pose(pw, m.b, Bb);
+            }
+        }
+        __syncthreads();
+        BodyS me; BodyS none;
+        if (has_slot && dynamic) {
+            body_load(pw, slot, me);
+            for (int j = 0; j < 4; ++j)
+                if (j < g_np) g_lam[j] += solve_point_position<false>(me, none, g_n, hull_local_vertex(obj, g_vi[j]), V3{0.f, 0.f, 0.f}, g_off[j], g_muS);
+            const int nsc = pw.nsc;
+            for (int k = 0; k < nsc; ++k) {
+                if (pw.scBody[k] != slot) continue;
+                ManS &m = pw.sc[k];
+                if (m.np <= 0) continue;
+                const V3 n = ld3(m.n);
+                for (int j = 0; j < m.np; ++j)
+                    m.lam[j] += solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+            }
+            // ---------- P5: derive velocities ----------
+            const float h = kSubstepH;
+            me.lin = (me.pos - me.ppos) * (1.f / h);
+            Q dq = qmul(me.rot, qinv(me.prot));
+            V3 wv = V3{dq.x, dq.y, dq.z} * (2.f / h);
+            me.ang = dq.w >= 0.f ? wv : -wv;
+            body_store_pose(pw, slot, me); body_store_vel(pw, slot, me);
+        }
+        __syncthreads();
+        // ---------- P6: velocity solve ----------
+        if (wok && l == 0) {
+            const int ndd = pw.ndd;
+            for (int k = 0; k < ndd; ++k) {
+                const ManDD &m = pw.dd[k];
+                if (m.np <= 0) continue;
+                BodyS Ab, Bb;
+                body_load(pw, m.a, Ab); body_load(pw, m.b, Bb);
+                const V3 n = ld3(m.n);
+                for (int j = 0; j < m.np; ++j)
+                    solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
+                body_store_vel(pw, m.a, Ab); body_store_vel(pw, m.b, Bb);
+            }
+        }
+        __syncthreads();
+        if (has_slot && dynamic) {
+            body_load(pw, slot, me);
+            for (int j = 0; j < 4; ++j)
+                if (j < g_np) solve_point_velocity<false>(me, none, g_n, hull_local_vertex(obj, g_vi[j]), V3{0.f, 0.f, 0.f}, g_lam[j], g_muD);
+            const int nsc = pw.nsc;
+            for (int k = 0; k < nsc; ++k) {
+                if (pw.scBody[k] != slot) continue;
+                const ManS &m = pw.sc[k];
+                if (m.np <= 0) continue;
+                const V3 n = ld3(m.n);
+                for (int j = 0; j < m.np; ++j)
+                    solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
+            }
+            body_store_vel(pw, slot, me);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- agentZeroVelSystem (sim.cpp:258-268) ----------------
+    if (instant && has_slot && agent >= 0 && pw.g.meta[slot] != 0) {
+        pw.lin[slot][0] = 0.f; pw.lin[slot][1] = 0.f; pw.lin[slot][2] = fminf(pw.lin[slot][2], 0.f);
+        pw.ang[slot][0] = 0.f; pw.ang[slot][1] = 0.f; pw.ang[slot][2] = 0.f;
+    }
+    __syncthreads();
+
+    // ---------------- rewardsVisSystem (sim.cpp:763-804): lanes = (seeker, hider) pairs ----------------
+    bool seen = false;
+    if (wok && l < 9) {
+        const int si = l / 3, hi_ = l % 3;
+        if (si < cnt_seekers(pw.counts) && hi_ < cnt_hiders(pw.counts)) {
+            const int ss = kAgentSlot0 + team_seeker(pw.teams, si), hs_ = kAgentSlot0 + team_hider(pw.teams, hi_);
+            const V3 spos = geom_pos(pw.g, ss);
+            const V3 fwd = qrot(geom_rot(pw.g, ss), {0.f, 1.f, 0.f});
+            V3 to = geom_pos(pw.g, hs_) - spos;
+            float c = dot(normalize(to), fwd);
+            if (!(c < kCosFovHalf)) {
+                float t;
+                seen = trace_ray(pw.g, spos, to, 1.f, &t) == hs_;
+            }
+        }
+    }
+    if (seen) pw.hiderReward = -1.f;      // every writer stores the same value
+    __syncthreads();
+
+    // ---------------- outputRewardsDonesSystem (sim.cpp:806-841) ----------------
+    if (is_agent_lane && team_agent_active(pw.teams, agent)) {
+        const int row = w * A_ + agent;
+        const int step = pw.step;
+        if (step == 0) S.xDone[row] = 0;
+        if (step < kNumPrepSteps - 1) {
+            S.xReward[row] = 0.f;
+        } else {
+            if (step == kEpisodeLen - 1) S.xDone[row] = 1;
+            float r = pw.hiderReward;
+            if (team_agent_type(pw.teams, agent) == AGENT_SEEKER) r *= -1.f;
+            if (fabsf(pw.g.pos[slot][0]) >= 18.f || fabsf(pw.g.pos[slot][1]) >= 18.f) r -= 10.f;
+            S.xReward[row] = r;
+        }
+    }
+    // ---------------- updateEpisodeResultsSystem (sim.cpp:843-893) ----------------
+    if (wok && l == 0) {
+        float *res = S.xEpisodeResult + w * 2;
+        const int step = pw.step;
+        int s0 = S.runningScores[0 * N + w], s1 = S.runningScores[1 * N + w];
+        if (step == 0) { res[0] = 0.f; res[1] = 0.f; s0 = 0; s1 = 0; }
+        if (step >= kNumPrepSteps) {
+            const bool hidden = pw.hiderReward == 1.f;
+            const bool sf = cnt_seekers_first(pw.counts) != 0;
+            const int win = hidden ? (sf ? 1 : 0) : (sf ? 0 : 1);
+            if (win == 0) s0 += 1; else s1 += 1;
+        }
+        if (step == kEpisodeLen - 1) {
+            if (s0 > s1) { res[0] = 1.f; res[1] = 0.f; }
+            else if (s0 < s1) { res[0] = 0.f; res[1] = 1.f; }
+            else { res[0] = 0.5f; res[1] = 0.5f; }
+        }
+        S.runningScores[0 * N + w] = s0; S.runningScores[1 * N + w] = s1;
+        S.hiderTeamReward[w] = pw.hiderReward;
+    }
+
+    // ---------------- write the world back to HBM ----------------
+    if (wok) {
+        for (int s = l; s < kNumDSlots; s += G) {
+            S.bmeta[s * N + w] = pw.g.meta[s];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                S.bpos[(c * kNumDSlots + s) * N + w] = pw.g.pos[s][c];
+                S.blin[(c * kNumDSlots + s) * N + w] = pw.lin[s][c];
+                S.bang[(c * kNumDSlots + s) * N + w] = pw.ang[s][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S.brot[(c * kNumDSlots + s) * N + w] = pw.g.rot[s][c];
+        }
+        for (int i = l; i < kMaxAgents; i += G) {
+            S.grabOther[i * N + w] = pw.grabOther[i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) S.grabData[(c * kMaxAgents + i) * N + w] = pw.grabData[i][c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S.aforce[(c * kMaxAgents + i) * N + w] = pw.aforce[i][c];
+        }
+    }
+}
+
+}  // namespace hs

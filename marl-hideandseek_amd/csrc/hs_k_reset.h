@@ -1,0 +1,397 @@
+// Episode reset kernel: resetSystem (src/sim.cpp:172-200) with the level generator
+// (src/level_gen.cpp, src/geo_gen.cpp) — one lane per world.
+//
+// The generator is serial and branchy per world (rejection sampling, wall splitting); it runs
+// once per 240 steps, so it is mapped lane-per-world with the world-fastest SoA layout giving
+// coalesced stores, and its divergence is accepted.  Integer decisions are gated
+// by float compares, so the arithmetic below is order-for-order the oracle's.
+#pragma once
+#include "hs_state.h"
+
+namespace hs {
+
+struct Seg { float x1, y1, x2, y2; };
+struct AABB { V3 lo, hi; };
+
+HSD Seg seg_make(float ax, float ay, float bx, float by) {     // geo_gen.cpp:60-65
+    if (ax > bx || ay > by) return {bx, by, ax, ay};
+    return {ax, ay, bx, by};
+}
+HSD void seg_resort(Seg &s) {                                  // geo_gen.cpp:71-77
+    if (s.x1 > s.x2 || s.y1 > s.y2) { Seg t = s; s = {t.x2, t.y2, t.x1, t.y1}; }
+}
+HSD bool seg_horizontal(const Seg &s) { return fabsf(s.y1 - s.y2) < 0.000001f; }   // :67-69
+HSD float seg_length(const Seg &s) { return seg_horizontal(s) ? (s.x2 - s.x1) : (s.y2 - s.y1); }
+
+struct WallSet {                                               // geo_gen.cpp:139-175
+    Seg segs[kMaxWalls]; int n;
+    uint8_t horiz[kMaxWalls]; int nh;
+    uint8_t vert[kMaxWalls]; int nv;
+};
+HSD int wallset_add(WallSet &w, Seg s) {
+    if (w.n >= kMaxWalls) return w.n - 1;
+    if (seg_horizontal(s)) w.horiz[w.nh++] = (uint8_t)w.n;
+    else w.vert[w.nv++] = (uint8_t)w.n;
+    w.segs[w.n++] = s;
+    return w.n - 1;
+}
+
+// geo_gen.cpp:177-270
+HSD int find_facing_wall(const WallSet &w, bool hz, int chosen_i, RNG &rng) {
+    const uint8_t *list = hz ? w.horiz : w.vert;
+    const int ln = hz ? w.nh : w.nv;
+    const float min_len = hz ? 0.3f : 0.5f;
+    const Seg c = w.segs[list[chosen_i]];
+    const float c_lo = hz ? c.x1 : c.y1, c_hi = hz ? c.x2 : c.y2, c_ac = hz ? c.y1 : c.x1;
+    const float c_len = seg_length(c);
+    int start = chosen_i + 1 + rng.sampleI32(0, ln - 1);
+    for (int i = 0; i < ln - 1; ++i) {
+        int cur = (start + i) % ln;
+        if (cur == chosen_i) cur = (cur + 1) % ln;
+        const Seg o = w.segs[list[cur]];
+        const float o_lo = hz ? o.x1 : o.y1, o_hi = hz ? o.x2 : o.y2, o_ac = hz ? o.y1 : o.x1;
+        if (!(c_lo >= o_hi || c_hi <= o_lo) && c_len >= min_len && seg_length(o) >= min_len) {
+            float high = fminf(c_hi, o_hi);
+            float low = fmaxf(c_lo, o_lo);
+            bool works = true;
+            for (int j = 0; j < ln; ++j) {
+                if (j == cur) continue;
+                const Seg b = w.segs[list[j]];
+                float bl = fmaxf(hz ? b.x1 : b.y1, low - 0.1f);
+                float bh = fminf(hz ? b.x2 : b.y2, high + 0.1f);
+                if (bl < bh) {
+                    float v = hz ? b.y1 : b.x1;
+                    float vmin = fminf(c_ac, o_ac);
+                    float vmax = fmaxf(c_ac, o_ac);
+                    if (v > vmin && v < vmax) { works = false; break; }
+                }
+            }
+            if (works) return cur;
+        }
+    }
+    return -1;
+}
+
+HSD void cut_door(WallSet &w, int wi, float door, RNG &rng) {   // geo_gen.cpp:275-307
+    Seg s = w.segs[wi];
+    float rat = 0.3f + rng.sampleUniform() * 0.4f;
+    Seg ns;
+    if (seg_horizontal(s)) {
+        float low = s.x1 + door, high = s.x2 - door;
+        float x = low + rat * (high - low);
+        float old = s.x2;
+        s.x2 = x - door * 0.5f;
+        seg_resort(s);
+        ns = seg_make(x + door * 0.5f, s.y1, old, s.y1);
+    } else {
+        float low = s.y1 + door, high = s.y2 - door;
+        float y = low + rat * (high - low);
+        float old = s.y2;
+        s.y2 = y - door * 0.5f;
+        seg_resort(s);
+        ns = seg_make(s.x1, y + door * 0.5f, s.x1, old);
+    }
+    w.segs[wi] = s;
+    wallset_add(w, ns);
+}
+
+HSD void wall_op_connect(WallSet &w, RNG &rng) {               // geo_gen.cpp:311-409
+    bool hz = rng.sampleI32(0, 2) != 0;
+    int ln = hz ? w.nh : w.nv;
+    int wi = rng.sampleI32(0, ln);
+    int oi;
+    int counter = 0;
+    while ((oi = find_facing_wall(w, hz, wi, rng)) == -1) {
+        hz = rng.sampleI32(0, 2) != 0;
+        ln = hz ? w.nh : w.nv;
+        wi = rng.sampleI32(0, ln);
+        if (counter++ > 4) return;
+    }
+    const uint8_t *list = hz ? w.horiz : w.vert;
+    int fi = list[wi], si = list[oi];
+    const float kDoor = 0.1f;
+    Seg f = w.segs[fi], s = w.segs[si];
+    if (hz) {
+        float high = fminf(f.x2, s.x2);
+        float low = fmaxf(f.x1, s.x1);
+        if (f.y1 > s.y1) { int t = fi; fi = si; si = t; Seg ts = f; f = s; s = ts; }
+        float rat = 0.4f + rng.sampleUniform() * 0.2f;
+        float x = low + rat * (high - low);
+        int ni = wallset_add(w, seg_make(x, f.y1, x, s.y1));
+        float fold = f.x2, sold = s.x2;
+        f.x2 = x; seg_resort(f);
+        s.x2 = x; seg_resort(s);
+        w.segs[fi] = f; w.segs[si] = s;
+        wallset_add(w, seg_make(x, f.y1, fold, f.y1));
+        wallset_add(w, seg_make(x, s.y1, sold, s.y1));
+        cut_door(w, ni, kDoor, rng);
+    } else {
+        float high = fminf(f.y2, s.y2);
+        float low = fmaxf(f.y1, s.y1);
+        if (f.x1 > s.x1) { int t = fi; fi = si; si = t; Seg ts = f; f = s; s = ts; }
+        float rat = 0.4f + rng.sampleUniform() * 0.2f;
+        float y = low + rat * (high - low);
+        int ni = wallset_add(w, seg_make(f.x1, y, s.x1, y));
+        float fold = f.y2, sold = s.y2;
+        f.y2 = y; seg_resort(f);
+        s.y2 = y; seg_resort(s);
+        w.segs[fi] = f; w.segs[si] = s;
+        wallset_add(w, seg_make(f.x1, y, f.x1, fold));
+        wallset_add(w, seg_make(s.x1, y, s.x1, sold));
+        cut_door(w, ni, kDoor, rng);
+    }
+}
+
+HSD void wall_op_add_door(WallSet &w, RNG &rng) {              // geo_gen.cpp:411-421
+    const float door = 0.1f * 2.0f;
+    int wi = rng.sampleI32(0, w.n);
+    if (seg_length(w.segs[wi]) > 3.0f * door) cut_door(w, wi, door, rng);
+}
+
+HSD void make_walls(WallSet &w, RNG &rng) {                    // geo_gen.cpp:429-465, 96-137
+    w.n = w.nh = w.nv = 0;
+    wallset_add(w, seg_make(0.f, 0.f, 1.f, 0.f));
+    wallset_add(w, seg_make(0.f, 0.f, 0.f, 1.f));
+    wallset_add(w, seg_make(0.f, 1.f, 1.f, 1.f));
+    wallset_add(w, seg_make(1.f, 1.f, 1.f, 0.f));
+    int c0 = 1 + rng.sampleI32(0, 6);
+    int c1 = 4 + rng.sampleI32(0, 3);
+    int op0 = 0, op1 = 1, nsel = 2;
+    do {
+        int oi = rng.sampleI32(0, nsel);
+        int op = oi == 0 ? op0 : op1;
+        int left = op == 0 ? --c0 : --c1;
+        if (left == 0) { --nsel; if (oi == 0) op0 = (nsel == 1) ? op1 : op0; }
+        if (op == 0) wall_op_connect(w, rng); else wall_op_add_door(w, rng);
+    } while (c0 != 0 || c1 != 0);
+}
+
+// AABB::applyTRS with unit scale (level_gen.cpp:142-143)
+HSD AABB aabb_apply_tr(AABB b, V3 t, Q r) {
+    M3 m = m3_from_quat(r);
+    m.c0 = m.c0 * 1.f; m.c1 = m.c1 * 1.f; m.c2 = m.c2 * 1.f;
+    float lo[3] = {t.x, t.y, t.z}, hi[3] = {t.x, t.y, t.z};
+    const float mm[3][3] = {{m.c0.x, m.c1.x, m.c2.x}, {m.c0.y, m.c1.y, m.c2.y}, {m.c0.z, m.c1.z, m.c2.z}};
+    const float bl[3] = {b.lo.x, b.lo.y, b.lo.z}, bh[3] = {b.hi.x, b.hi.y, b.hi.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float e = mm[i][j] * bl[j], f = mm[i][j] * bh[j];
+            if (e < f) { lo[i] += e; hi[i] += f; } else { lo[i] += f; hi[i] += e; }
+        }
+    }
+    return {{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+}
+HSD AABB object_aabb(int obj) {
+    if (obj == OBJ_RAMP) return {{-1.f, -2.f, -1.f}, {1.f, 1.f, 1.f}};
+    if (obj == OBJ_BOX) return {{-4.f, -0.75f, -1.f}, {4.f, 0.75f, 1.f}};
+    return {{-1.f, -1.f, -1.f}, {1.f, 1.f, 1.f}};
+}
+HSD bool aabb_overlaps(const AABB &a, const AABB &b) {
+    return a.lo.x < b.hi.x && b.lo.x < a.hi.x && a.lo.y < b.hi.y && b.lo.y < a.hi.y &&
+           a.lo.z < b.hi.z && b.lo.z < a.hi.z;
+}
+
+// Per-lane working copy of the world being generated.
+struct GenWorld {
+    int numWalls; float wcx[kMaxWalls], wcy[kMaxWalls], whx[kMaxWalls], why[kMaxWalls];
+    int obj[kNumDSlots]; V3 pos[kNumDSlots]; Q rot[kNumDSlots]; int resp[kNumDSlots]; int owner[kNumDSlots];
+    V3 lin[kNumDSlots];
+    int numPlanes; V3 pn[kMaxPlanes]; float pd[kMaxPlanes];
+    int numHiders, numSeekers, numActiveAgents, numActiveBoxes, numActiveRamps, seekersFirst;
+    int hiders[3], seekers[3]; int agentType[kMaxAgents];
+};
+
+HSD void gen_put(GenWorld &g, int slot, V3 p, Q r, int obj, int resp = RESP_DYNAMIC, int owner = OWNER_NONE) {
+    g.obj[slot] = obj; g.pos[slot] = p; g.rot[slot] = r; g.resp[slot] = resp; g.owner[slot] = owner;
+    g.lin[slot] = {0.f, 0.f, 0.f};
+}
+HSD void gen_agent(GenWorld &g, V3 p, Q r, int type) {          // makeAgent level_gen.cpp:12-66
+    int idx = g.numActiveAgents++;
+    g.agentType[idx] = type;
+    gen_put(g, kAgentSlot0 + idx, p, r, type == AGENT_SEEKER ? OBJ_SEEKER : OBJ_HIDER, RESP_DYNAMIC, OWNER_UNOWNABLE);
+    if (type == AGENT_SEEKER) g.seekers[g.numSeekers++] = idx; else g.hiders[g.numHiders++] = idx;
+}
+HSD void gen_plane(GenWorld &g, V3 n, float d) { g.pn[g.numPlanes] = n; g.pd[g.numPlanes] = d; g.numPlanes++; }
+
+HSD bool placement_free(const GenWorld &g, const AABB &a) {     // level_gen.cpp:104-121
+    for (int i = 0; i < g.numWalls; ++i) {
+        AABB o = {{g.wcx[i] - g.whx[i], g.wcy[i] - g.why[i], 0.f}, {g.wcx[i] + g.whx[i], g.wcy[i] + g.why[i], 2.5f}};
+        if (aabb_overlaps(a, o)) return false;
+    }
+    for (int s = 0; s < kAgentSlot0; ++s) {
+        if (g.obj[s] == OBJ_NONE) continue;
+        AABB o = aabb_apply_tr(object_aabb(g.obj[s]), g.pos[s], g.rot[s]);
+        if (aabb_overlaps(a, o)) return false;
+    }
+    return true;
+}
+HSD void sample_placement(const GenWorld &g, RNG &rng, int obj, V3 *pos_out, Q *rot_out) {   // :123-229
+    const float lo = -18.f, diff = 18.f - (-18.f);
+    int rejections = 0;
+    while (true) {
+        float px = lo + rng.sampleUniform() * diff;
+        float py = lo + rng.sampleUniform() * diff;
+        V3 pos = {px, py, 1.0f};
+        float theta = rng.sampleUniform() * kPi;
+        Q rot = quat_angle_axis_z(theta);
+        AABB a = aabb_apply_tr(object_aabb(obj), pos, rot);
+        if (placement_free(g, a) || rejections == 20) { *pos_out = pos; *rot_out = rot; return; }
+        rejections++;
+    }
+}
+
+HSD void gen_training(GenWorld &g, RNG &rng, RNG &episode_rng, uint32_t flags, int num_hiders, int num_seekers) {
+    int total_boxes = rng.sampleI32(3, 10);
+    int num_elongated = rng.sampleI32(3, total_boxes);
+    int num_cubes = total_boxes - num_elongated;
+    {   // populateStaticGeometry geo_gen.cpp:467-505
+        WallSet ws;
+        make_walls(ws, rng);
+        const float mn = -18.f, range = 18.f - (-18.f);
+        g.numWalls = ws.n;
+        for (int i = 0; i < ws.n; ++i) {
+            Seg s = ws.segs[i];
+            s.x1 = mn + range * s.x1; s.y1 = mn + range * s.y1;
+            s.x2 = mn + range * s.x2; s.y2 = mn + range * s.y2;
+            float cx = 0.5f * (s.x1 + s.x2), cy = 0.5f * (s.y1 + s.y2);
+            g.wcx[i] = cx; g.wcy[i] = cy;
+            if (seg_horizontal(s)) { g.whx[i] = s.x2 - cx; g.why[i] = 0.2f; }
+            else { g.whx[i] = 0.2f; g.why[i] = s.y2 - cy; }
+        }
+    }
+    V3 p; Q r;
+    for (int i = 0; i < num_elongated; ++i) { sample_placement(g, rng, OBJ_BOX, &p, &r); gen_put(g, kBoxSlot0 + i, p, r, OBJ_BOX); }
+    for (int i = 0; i < num_cubes; ++i) { sample_placement(g, rng, OBJ_CUBE, &p, &r); gen_put(g, kBoxSlot0 + num_elongated + i, p, r, OBJ_CUBE); }
+    g.numActiveBoxes = total_boxes;
+    for (int i = 0; i < kMaxRamps; ++i) { sample_placement(g, rng, OBJ_RAMP, &p, &r); gen_put(g, kRampSlot0 + i, p, r, OBJ_RAMP); }
+    g.numActiveRamps = kMaxRamps;
+    bool seekers_first = episode_rng.sampleI32(0, 2) == 1;       // level_gen.cpp:232-238
+    if ((flags & FLAG_RANDOM_FLIP_TEAMS) != FLAG_RANDOM_FLIP_TEAMS) seekers_first = false;
+    g.seekersFirst = seekers_first ? 1 : 0;
+    for (int t = 0; t < 2; ++t) {
+        int type = (t == 0) == seekers_first ? AGENT_SEEKER : AGENT_HIDER;
+        int cnt = type == AGENT_SEEKER ? num_seekers : num_hiders;
+        for (int i = 0; i < cnt; ++i) {
+            sample_placement(g, rng, type == AGENT_SEEKER ? OBJ_SEEKER : OBJ_HIDER, &p, &r);
+            gen_agent(g, p, r, type);
+        }
+    }
+    gen_plane(g, {0.f, 0.f, 1.f}, 0.f);
+}
+
+HSD void gen_debug(GenWorld &g, int level) {                    // level_gen.cpp:336-526
+    const Q ident = {1.f, 0.f, 0.f, 0.f};
+    const V3 up = {0.f, 0.f, 1.f};
+    if (level == 2) { gen_put(g, 0, {0, 0, 5}, {0.880476236f, 0.364705205f, 0.279848129f, -0.115916893f}, OBJ_CUBE); gen_plane(g, up, 0.f); }
+    else if (level == 3) { gen_put(g, 0, {0, 0, 5}, ident, OBJ_CUBE); gen_plane(g, up, 0.f); }
+    else if (level == 4) { gen_put(g, 0, {0, 0, 10}, {0.923879504f, 0.f, 0.382683426f, 0.f}, OBJ_BOX); gen_plane(g, up, 0.f); }
+    else if (level == 5) { gen_plane(g, up, 0.f); gen_agent(g, {0, 0, 1}, ident, AGENT_HIDER); }
+    else if (level == 6) {
+        gen_plane(g, up, 0.f);
+        g.wcx[0] = 0.f; g.wcy[0] = 0.f; g.whx[0] = 10.f; g.why[0] = 0.2f; g.numWalls = 1;
+        gen_put(g, 0, {0, -5, 1}, ident, OBJ_CUBE);
+        gen_agent(g, {-15, -15, 1.5f}, {0.923879504f, 0.f, 0.f, -0.382683426f}, AGENT_HIDER);
+        gen_agent(g, {-15, -10, 1.5f}, {0.923879504f, 0.f, 0.f, 0.382683426f}, AGENT_SEEKER);
+    } else if (level == 7) {
+        const Q rot = {0.868162751f, 0.315985411f, 0.359604806f, -0.130885437f};
+        gen_put(g, 0, {0, 0, 5}, rot, OBJ_CUBE);
+        gen_put(g, 1, {0, 0, 10}, rot, OBJ_CUBE);
+        gen_plane(g, up, 0.f); gen_plane(g, {1.f, 0.f, 0.f}, -20.f); gen_plane(g, {-1.f, 0.f, 0.f}, -20.f);
+    } else if (level == 8) {
+        gen_put(g, kRampSlot0, {0, 0, 10}, {0.579227984f, 0.405579776f, 0.405579776f, 0.579227984f}, OBJ_RAMP);
+        g.lin[kRampSlot0] = {0.f, 0.f, -30.f};
+        gen_put(g, kRampSlot0 + 1, {-0.5f, -0.5f, 1.f}, {0.f, 0.f, 0.707106769f, -0.707106769f}, OBJ_RAMP, RESP_STATIC, OWNER_NONE);
+        gen_plane(g, up, 0.f); gen_plane(g, {1.f, 0.f, 0.f}, -20.f); gen_plane(g, {-1.f, 0.f, 0.f}, -20.f);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_reset(SimState S) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = S.N;
+    if (w >= N) return;
+    int level = S.xReset[w];
+    const int step = S.curEpisodeStep[w];
+    if ((S.flags & FLAG_IGNORE_EPISODE_LENGTH) != FLAG_IGNORE_EPISODE_LENGTH && step == kEpisodeLen - 1) level = 1;
+    if (level == 0) {
+        S.curEpisodeStep[w] = step + 1;
+        S.hiderTeamReward[w] = 1.f;
+        return;
+    }
+    // ---- resetEnvironment + initEpisodeRNG (sim.cpp:105-159)
+    S.xReset[w] = 0;
+    uint32_t ep = S.curWorldEpisode[w];
+    S.curWorldEpisode[w] = ep + 1;
+    const uint32_t world_id = (uint32_t)(S.worldOffset + w);
+    RNG erng; erng.k = threefry2x32(S.initKey, ep, world_id); erng.count = 0;
+    int nh = erng.sampleI32(S.minHiders, S.maxHiders + 1);
+    int ns = erng.sampleI32(S.minSeekers, S.maxSeekers + 1);
+    RandKey lvl = erng.randKey();
+    if ((S.flags & FLAG_USE_FIXED_WORLD) == FLAG_USE_FIXED_WORLD) lvl = {0u, 0u};
+
+    GenWorld g;
+    g.numWalls = 0; g.numPlanes = 0;
+    g.numHiders = g.numSeekers = g.numActiveAgents = g.numActiveBoxes = g.numActiveRamps = 0;
+    g.seekersFirst = cnt_seekers_first(S.counts[w]);   // TeamState persists across debug levels
+    for (int i = 0; i < 3; ++i) { g.hiders[i] = 0; g.seekers[i] = 0; }
+    for (int i = 0; i < kMaxAgents; ++i) g.agentType[i] = team_agent_type(S.teams[w], i);
+    for (int i = 0; i < kNumDSlots; ++i) {
+        g.obj[i] = OBJ_NONE; g.pos[i] = {0.f, 0.f, 0.f}; g.rot[i] = {1.f, 0.f, 0.f, 0.f};
+        g.resp[i] = RESP_STATIC; g.owner[i] = OWNER_NONE; g.lin[i] = {0.f, 0.f, 0.f};
+    }
+    RNG lrng; lrng.k = lvl; lrng.count = 0;
+    if (level == 1) gen_training(g, lrng, erng, S.flags, nh, ns);
+    else gen_debug(g, level);
+
+    // ---- write back
+    S.rngKeyA[w] = erng.k.a; S.rngKeyB[w] = erng.k.b; S.rngCount[w] = erng.count;
+    S.curEpisodeStep[w] = 0;
+    S.hiderTeamReward[w] = 1.f;
+    S.numWalls[w] = g.numWalls; S.numPlanes[w] = g.numPlanes;
+    for (int i = 0; i < g.numWalls; ++i) {
+        S.walls[(0 * kMaxWalls + i) * N + w] = g.wcx[i]; S.walls[(1 * kMaxWalls + i) * N + w] = g.wcy[i];
+        S.walls[(2 * kMaxWalls + i) * N + w] = g.whx[i]; S.walls[(3 * kMaxWalls + i) * N + w] = g.why[i];
+    }
+    for (int p = 0; p < g.numPlanes; ++p) {
+        S.planes[(0 * kMaxPlanes + p) * N + w] = g.pn[p].x; S.planes[(1 * kMaxPlanes + p) * N + w] = g.pn[p].y;
+        S.planes[(2 * kMaxPlanes + p) * N + w] = g.pn[p].z; S.planes[(3 * kMaxPlanes + p) * N + w] = g.pd[p];
+    }
+    for (int i = 0; i < kNumDSlots; ++i) {
+        S.bmeta[i * N + w] = g.obj[i] == OBJ_NONE ? 0 : meta_pack(g.obj[i], g.resp[i], g.owner[i]);
+        S.bpos[(0 * kNumDSlots + i) * N + w] = g.pos[i].x; S.bpos[(1 * kNumDSlots + i) * N + w] = g.pos[i].y;
+        S.bpos[(2 * kNumDSlots + i) * N + w] = g.pos[i].z;
+        S.brot[(0 * kNumDSlots + i) * N + w] = g.rot[i].w; S.brot[(1 * kNumDSlots + i) * N + w] = g.rot[i].x;
+        S.brot[(2 * kNumDSlots + i) * N + w] = g.rot[i].y; S.brot[(3 * kNumDSlots + i) * N + w] = g.rot[i].z;
+        S.blin[(0 * kNumDSlots + i) * N + w] = g.lin[i].x; S.blin[(1 * kNumDSlots + i) * N + w] = g.lin[i].y;
+        S.blin[(2 * kNumDSlots + i) * N + w] = g.lin[i].z;
+        S.bang[(0 * kNumDSlots + i) * N + w] = 0.f; S.bang[(1 * kNumDSlots + i) * N + w] = 0.f;
+        S.bang[(2 * kNumDSlots + i) * N + w] = 0.f;
+    }
+    int teams = 0;
+    for (int i = 0; i < 3; ++i) { teams |= (g.hiders[i] & 7) << (3 * i); teams |= (g.seekers[i] & 7) << (9 + 3 * i); }
+    for (int i = 0; i < kMaxAgents; ++i) {
+        teams |= (g.agentType[i] & 1) << (18 + i);
+        if (i < g.numActiveAgents) teams |= 1 << (24 + i);
+        S.grabOther[i * N + w] = -1;
+        for (int c = 0; c < 4; ++c) S.aforce[(c * kMaxAgents + i) * N + w] = 0.f;
+    }
+    S.teams[w] = teams;
+    S.counts[w] = cnt_pack(g.numHiders, g.numSeekers, g.numActiveAgents, g.numActiveBoxes, g.numActiveRamps, g.seekersFirst);
+    // exported agent-interface columns (makeAgent level_gen.cpp:16-32; generateEnvironment :326-333)
+    const int A = S.A;
+    for (int i = 0; i < A; ++i) {
+        int row = w * A + i;
+        if (i < g.numActiveAgents) {
+            S.xSelfType[row] = g.agentType[i];
+            S.xSelfMask[row] = 1.f;
+            S.xSeed[row * 2 + 0] = (int32_t)ep; S.xSeed[row * 2 + 1] = (int32_t)world_id;
+            int32_t *a = S.xAction + row * 5;
+            a[0] = 2; a[1] = 2; a[2] = 2; a[3] = 0; a[4] = 0;
+        } else {
+            S.xSelfMask[row] = 0.f;
+        }
+    }
+}
+
+}  // namespace hs

@@ -1,0 +1,94 @@
+// Ray casting against one world's geometry staged in LDS — the build's replacement for
+// madrona::phys::broadphase::BVH::traceRay (call sites src/sim.cpp:288,331,602,738,797).
+//
+// A world holds at most 17 movable hulls, 36 axis-aligned walls and 3 planes, so the "BVH" is a
+// flat list walked by every lane; all lanes of a workgroup read the same LDS words (broadcast, no
+// bank conflicts).  Semantics (DESIGN.md "Engine decisions"): closest front-face entry with
+// 0 <= t <= t_max in units of |d|; a ray starting inside a hull does not hit that hull; ties keep
+// the lower body id.  Body ids: 0..16 movable slots, 100+k walls, 200+p planes, -1 miss.
+#pragma once
+#include "hs_dev.h"
+
+namespace hs {
+
+constexpr int kHitWallBase = 100;
+constexpr int kHitPlaneBase = 200;
+
+struct WorldGeom {
+    int meta[kNumDSlots];
+    float pos[kNumDSlots][3];
+    float rot[kNumDSlots][4];
+    int numWalls, numPlanes;
+    float wall[kMaxWalls][4];     // cx, cy, hx, hy
+    float plane[kMaxPlanes][4];   // nx, ny, nz, d
+};
+
+HSD V3 geom_pos(const WorldGeom &g, int i) { return {g.pos[i][0], g.pos[i][1], g.pos[i][2]}; }
+HSD Q geom_rot(const WorldGeom &g, int i) { return {g.rot[i][0], g.rot[i][1], g.rot[i][2], g.rot[i][3]}; }
+
+HSD float ray_box_local(V3 o, V3 d, V3 e) {
+    float tn = -3.0e38f, tf = 3.0e38f;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ee[3] = {e.x, e.y, e.z};
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) miss = true; continue; }
+        float inv = 1.f / dd[k];
+        float t0 = (-ee[k] - oo[k]) * inv, t1 = (ee[k] - oo[k]) * inv;
+        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+    }
+    if (miss || tn > tf || tn < 0.f) return -1.f;
+    return tn;
+}
+
+HSD float ray_wedge_local(V3 o, V3 d) {
+    float tn = -3.0e38f, tf = 3.0e38f;
+    const float fn[5][3] = {{0, 0, -1}, {0, 1, 0}, {0, -0.554700196f, 0.832050294f}, {1, 0, 0}, {-1, 0, 0}};
+    const float off[5] = {1.f, 1.f, 0.277350098f, 1.f, 1.f};
+    bool miss = false;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        V3 n = {fn[f][0], fn[f][1], fn[f][2]};
+        float dist = dot(n, o) - off[f];
+        float dn = dot(n, d);
+        if (dn == 0.f) { if (dist > 0.f) miss = true; continue; }
+        float t = -dist / dn;
+        if (dn < 0.f) tn = fmaxf(tn, t); else tf = fminf(tf, t);
+    }
+    if (miss || tn > tf || tn < 0.f) return -1.f;
+    return tn;
+}
+
+HSD int trace_ray(const WorldGeom &g, V3 o, V3 d, float tmax, float *t_out) {
+    int hit = -1; float best = tmax;
+    for (int i = 0; i < kNumDSlots; ++i) {
+        int m = g.meta[i];
+        if (m == 0) continue;
+        int obj = meta_obj(m);
+        Q qi = qinv(geom_rot(g, i));
+        V3 ol = qrot(qi, o - geom_pos(g, i)), dl = qrot(qi, d);
+        float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
+        if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = i; }
+    }
+    const int nw = g.numWalls;
+    for (int k = 0; k < nw; ++k) {
+        V3 ol = {o.x - g.wall[k][0], o.y - g.wall[k][1], o.z - 1.25f};
+        float t = ray_box_local(ol, d, {g.wall[k][2], g.wall[k][3], 1.25f});
+        if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + k; }
+    }
+    const int np = g.numPlanes;
+    for (int p = 0; p < np; ++p) {
+        V3 n = {g.plane[p][0], g.plane[p][1], g.plane[p][2]};
+        float dn = dot(n, d);
+        if (!(dn < 0.f)) continue;
+        float dist = dot(n, o) - g.plane[p][3];
+        if (dist < 0.f) continue;
+        float t = -dist / dn;
+        if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitPlaneBase + p; }
+    }
+    *t_out = best;
+    return hit;
+}
+
+}  // namespace hs

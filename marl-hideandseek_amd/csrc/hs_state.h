@@ -1,0 +1,68 @@
+// Simulator state in HBM.
+//
+// Internal entity-component columns are struct-of-arrays ACROSS WORLDS: element (field f, slot s,
+// world w) lives at base[(f*SLOTS + s)*N + w], so a wave whose lanes walk consecutive worlds (or a
+// group that loads one world's slots) issues coalesced dword loads.  This replaces Madrona's ECS
+// archetype tables: every capacity is a small compile-time bound
+// (src/sim.hpp:39-41), so slots are fixed and nothing is ever compacted or sorted.
+//
+// Exported tensors keep the reference's contract instead (AoS, row-major, agent row =
+// world*A + slot; src/mgr.cpp:1062-1331) because scripts alias them in place.
+#pragma once
+#include "hs_dev.h"
+
+namespace hs {
+
+struct SimState {
+    int N;                 // worlds in this shard
+    int A;                 // maxAgentsPerWorld = maxHiders + maxSeekers (src/mgr.cpp:684)
+    uint32_t flags;        // SimFlags | extension bits
+    RandKey initKey;       // rand::initKey(seed) (src/mgr.cpp:678)
+    int minHiders, maxHiders, minSeekers, maxSeekers;
+    int worldOffset;
+
+    // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
+    float *bpos;           // [3][17][N]
+    float *brot;           // [4][17][N]  w,x,y,z
+    float *blin;           // [3][17][N]
+    float *bang;           // [3][17][N]
+    int *bmeta;            // [17][N]     meta_pack()
+    float *aforce;         // [4][6][N]   ExternalForce xyz + ExternalTorque z of the agents
+    // --- static geometry
+    float *walls;          // [4][36][N]  cx, cy, hx, hy
+    float *planes;         // [4][3][N]   nx, ny, nz, d
+    int *numWalls;         // [N]
+    int *numPlanes;        // [N]
+    // --- world scalars (Sim fields src/sim.hpp:326-362 and singletons :105-121)
+    uint32_t *curWorldEpisode;   // [N]
+    uint32_t *rngKeyA, *rngKeyB, *rngCount;   // episode RNG
+    int *curEpisodeStep;         // [N]
+    float *hiderTeamReward;      // [N]
+    int *counts;    // [N] numHiders | numSeekers<<4 | numActiveAgents<<8 | numActiveBoxes<<12 | numActiveRamps<<16 | seekersFirst<<20
+    int *teams;     // [N] hiders[3] (3 bits each, bits 0-8), seekers[3] (bits 9-17), agentType[6] (bits 18-23), agentActive[6] (bits 24-29)
+    int *runningScores;          // [2][N]
+    // --- grab joints, one per agent slot
+    int *grabOther;        // [6][N]  D-slot or -1
+    float *grabData;       // [8][6][N]  r2 xyz, attach2 wxyz, separation
+
+    // --- exported columns (AoS)
+    int32_t *xReset, *xPrep, *xAction, *xSelfType, *xSeed, *xDone, *xPolicy;
+    float *xSelfObs, *xSelfMask, *xAgentObs, *xBoxObs, *xRampObs, *xVisAgents, *xVisBoxes, *xVisRamps;
+    float *xLidar, *xReward, *xGlobalPos, *xEpisodeResult;
+};
+
+HSD int cnt_hiders(int c) { return c & 15; }
+HSD int cnt_seekers(int c) { return (c >> 4) & 15; }
+HSD int cnt_agents(int c) { return (c >> 8) & 15; }
+HSD int cnt_boxes(int c) { return (c >> 12) & 15; }
+HSD int cnt_ramps(int c) { return (c >> 16) & 15; }
+HSD int cnt_seekers_first(int c) { return (c >> 20) & 1; }
+HSD int cnt_pack(int nh, int ns, int na, int nb, int nr, int sf) {
+    return nh | (ns << 4) | (na << 8) | (nb << 12) | (nr << 16) | (sf << 20);
+}
+HSD int team_hider(int t, int i) { return (t >> (3 * i)) & 7; }
+HSD int team_seeker(int t, int i) { return (t >> (9 + 3 * i)) & 7; }
+HSD int team_agent_type(int t, int i) { return (t >> (18 + i)) & 1; }
+HSD int team_agent_active(int t, int i) { return (t >> (24 + i)) & 1; }
+
+}  // namespace hs

@@ -20,9 +20,11 @@ namespace hsref {
 
 constexpr float kSubstepH = (1.f / 30.f) / 4.f;
 constexpr float kGravityZ = -9.8f;            // sim.cpp:1360
-constexpr int kMaxDDManifolds = 24;           // body-body manifolds per world per substep
-constexpr int kMaxSManifolds = 40;            // body-static manifolds per world per substep
-constexpr int kMaxSPerBody = 6;
+// Candidate-pair capacities per world per substep (pairs whose AABBs overlap; measured maxima on
+// the benchmark workload are 6 accepted body-body and 9 accepted body-wall manifolds).  Pairs
+// beyond the capacity are dropped in pair order, identically in the HIP kernels.
+constexpr int kMaxDDCand = 12;                // body-body candidate pairs
+constexpr int kMaxSCand = 24;                 // body-(wall | plane>=1) candidate pairs
 constexpr float kMaxDepenVel = 3.f;         // m/s, rate limit for pre-existing overlap
 
 // mgr.cpp:476-559 — inverse mass and friction per SimObject
@@ -155,13 +157,22 @@ struct Manifold {
     V3 n;
     int np;
     V3 rA[4];          // contact point in A's local frame
-    V3 rB[4];          // in B's local frame, or the world point when b == -1
+    V3 rB[4];          // in B's local frame (b >= 0 only)
+    float offB[4];     // b == -1: n . pB, the static surface point projected on the normal
     float lambdaN[4];
 };
 
-struct RawManifold { V3 n; int np; V3 pA[4]; V3 pB[4]; };
+struct RawManifold { V3 n; int np; V3 pA[4]; V3 pB[4]; int vidx[4]; };
 
-// Hull vs infinite plane (pn.p = pd): up to the 4 deepest vertices below the plane.
+// Local-frame hull vertex i (data/*_collision.obj)
+static inline V3 hull_local_vertex(int32_t obj, int i) {
+    if (obj == OBJ_RAMP) return {kWedgeV[i][0], kWedgeV[i][1], kWedgeV[i][2]};
+    V3 e = obj_half_extents(obj);
+    return {(i & 1) ? e.x : -e.x, (i & 2) ? e.y : -e.y, (i & 4) ? e.z : -e.z};
+}
+
+// Hull vs infinite plane (pn.p = pd): up to the 4 deepest vertices below the plane.  The contact
+// point on the hull is the vertex itself (vidx), the point on the plane its projection.
 static inline bool collide_hull_plane(const Hull &A, V3 pn, float pd, RawManifold &m) {
     int np = 0; float depth[4];
     for (int i = 0; i < A.nv; ++i) {
@@ -170,11 +181,11 @@ static inline bool collide_hull_plane(const Hull &A, V3 pn, float pd, RawManifol
         float dep = -dist;
         V3 pa = A.v[i];
         V3 pb = A.v[i] - pn * dist;
-        if (np < 4) { depth[np] = dep; m.pA[np] = pa; m.pB[np] = pb; np++; }
+        if (np < 4) { depth[np] = dep; m.pA[np] = pa; m.pB[np] = pb; m.vidx[np] = i; np++; }
         else {
             int mi = 0;
             for (int k = 1; k < 4; ++k) if (depth[k] < depth[mi]) mi = k;
-            if (dep > depth[mi]) { depth[mi] = dep; m.pA[mi] = pa; m.pB[mi] = pb; }
+            if (dep > depth[mi]) { depth[mi] = dep; m.pA[mi] = pa; m.pB[mi] = pb; m.vidx[mi] = i; }
         }
     }
     m.np = np; m.n = -pn;
@@ -377,15 +388,16 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
         V3 rAw = qrot(A->rot, m.rA[j]);
         V3 pA = A->pos + rAw;
         V3 rBw = B ? qrot(B->rot, m.rB[j]) : V3{0.f, 0.f, 0.f};
-        V3 pB = B ? B->pos + rBw : m.rB[j];
-        float d = dot(pA - pB, n);
+        V3 pB = B ? B->pos + rBw : V3{0.f, 0.f, 0.f};
+        float d = B ? dot(pA - pB, n) : dot(pA, n) - m.offB[j];
         if (!(d > 0.f)) continue;
         // Overlap that already existed at the start of the substep (spawn overlaps after 20
         // rejected placements, level_gen.cpp:146) is resolved at kMaxDepenVel instead of in one
         // substep; penetration gained during this substep is always resolved in full.
         V3 pAprev = A->prevPos + qrot(A->prevRot, m.rA[j]);
-        V3 pBprev = B ? B->prevPos + qrot(B->prevRot, m.rB[j]) : m.rB[j];
-        float excess = dot(pAprev - pBprev, n) - kMaxDepenVel * kSubstepH;
+        V3 pBprev = B ? B->prevPos + qrot(B->prevRot, m.rB[j]) : V3{0.f, 0.f, 0.f};
+        float dprev = B ? dot(pAprev - pBprev, n) : dot(pAprev, n) - m.offB[j];
+        float excess = dprev - kMaxDepenVel * kSubstepH;
         if (excess > 0.f) d = d - excess;
         if (!(d > 0.f)) continue;
         float wA = gen_inv_mass(A->rot, ma, rAw, n);
@@ -538,16 +550,16 @@ static inline void derive_velocity(DBody &b) {
 }
 
 static inline void manifold_from_raw(const World &w, Manifold &m, int a, int b, int32_t objB,
-                                     const RawManifold &raw) {
+                                     const RawManifold &raw, bool plane = false) {
     const DBody &A = w.d[a];
     m.a = a; m.b = b; m.n = raw.n; m.np = raw.np;
     m.muS = 0.5f * (obj_mu_s(A.objType) + obj_mu_s(objB));
     m.muD = 0.5f * (obj_mu_d(A.objType) + obj_mu_d(objB));
     Q qai = qinv(A.rot);
     for (int j = 0; j < raw.np; ++j) {
-        m.rA[j] = qrot(qai, raw.pA[j] - A.pos);
-        if (b >= 0) m.rB[j] = qrot(qinv(w.d[b].rot), raw.pB[j] - w.d[b].pos);
-        else m.rB[j] = raw.pB[j];
+        m.rA[j] = plane ? hull_local_vertex(A.objType, raw.vidx[j]) : qrot(qai, raw.pA[j] - A.pos);
+        if (b >= 0) { m.rB[j] = qrot(qinv(w.d[b].rot), raw.pB[j] - w.d[b].pos); m.offB[j] = 0.f; }
+        else { m.rB[j] = {0.f, 0.f, 0.f}; m.offB[j] = dot(raw.pB[j], raw.n); }
         m.lambdaN[j] = 0.f;
     }
 }
@@ -560,56 +572,75 @@ static inline void physics_substep(World &w) {
     for (int i = 0; i < kNumDSlots; ++i)
         if (w.d[i].objType != OBJ_NONE) hull_from_body(hulls[i], w.d[i].objType, w.d[i].pos, w.d[i].rot);
 
-    static thread_local Manifold dd[kMaxDDManifolds];
-    static thread_local Manifold sm[kMaxSManifolds];
-    int ndd = 0, nsm = 0;
-    RawManifold raw;
+    // --- candidate pairs (the "broadphase": all-pairs AABB tests)
+    int ddA[kMaxDDCand], ddB[kMaxDDCand]; int ndd = 0;
     for (int i = 0; i < kNumDSlots; ++i) {
         if (w.d[i].objType == OBJ_NONE) continue;
         for (int j = i + 1; j < kNumDSlots; ++j) {
             if (w.d[j].objType == OBJ_NONE) continue;
             if (w.d[i].response != RESP_DYNAMIC && w.d[j].response != RESP_DYNAMIC) continue;
             if (!hull_aabb_overlap(hulls[i], hulls[j])) continue;
-            if (ndd >= kMaxDDManifolds) continue;
-            if (collide_hulls(hulls[i], hulls[j], raw))
-                manifold_from_raw(w, dd[ndd++], i, j, w.d[j].objType, raw);
+            if (ndd < kMaxDDCand) { ddA[ndd] = i; ddB[ndd] = j; ndd++; }
         }
     }
-    int sFirst[kNumDSlots + 1];
+    // static candidates per movable body: planes 1.. (always), then walls whose AABB overlaps;
+    // plane 0 (the ground, present in every level) has a dedicated manifold per body.
+    int scBody[kMaxSCand], scStatic[kMaxSCand]; int nsc = 0;
     for (int i = 0; i < kNumDSlots; ++i) {
-        sFirst[i] = nsm;
         if (w.d[i].objType == OBJ_NONE || w.d[i].response != RESP_DYNAMIC) continue;
-        int nb = 0;
-        for (int p = 0; p < w.numPlanes; ++p) {
-            if (nb >= kMaxSPerBody || nsm >= kMaxSManifolds) break;
-            if (collide_hull_plane(hulls[i], w.planes[p].n, w.planes[p].d, raw)) {
-                manifold_from_raw(w, sm[nsm++], i, -1, OBJ_PLANE, raw); nb++;
-            }
-        }
+        for (int p = 1; p < w.numPlanes; ++p)
+            if (nsc < kMaxSCand) { scBody[nsc] = i; scStatic[nsc] = kMaxWalls + p; nsc++; }
+        const Hull &hb = hulls[i];
         for (int k = 0; k < w.numWalls; ++k) {
-            if (nb >= kMaxSPerBody || nsm >= kMaxSManifolds) break;
             const WallS &ws = w.walls[k];
-            const Hull &hb = hulls[i];
             if (!(hb.lo.x <= ws.cx + ws.hx && ws.cx - ws.hx <= hb.hi.x &&
                   hb.lo.y <= ws.cy + ws.hy && ws.cy - ws.hy <= hb.hi.y && hb.lo.z <= 2.5f && 0.f <= hb.hi.z))
                 continue;
-            Hull hw; hull_from_wall(hw, ws);
-            if (collide_hulls(hulls[i], hw, raw)) {
-                manifold_from_raw(w, sm[nsm++], i, -1, OBJ_WALL, raw); nb++;
-            }
+            if (nsc < kMaxSCand) { scBody[nsc] = i; scStatic[nsc] = k; nsc++; }
         }
     }
-    sFirst[kNumDSlots] = nsm;
 
+    // --- narrowphase
+    static thread_local Manifold dd[kMaxDDCand], sc[kMaxSCand], ground[kNumDSlots];
+    RawManifold raw;
+    for (int k = 0; k < ndd; ++k) {
+        dd[k].np = 0;
+        if (collide_hulls(hulls[ddA[k]], hulls[ddB[k]], raw))
+            manifold_from_raw(w, dd[k], ddA[k], ddB[k], w.d[ddB[k]].objType, raw);
+    }
+    for (int i = 0; i < kNumDSlots; ++i) {
+        ground[i].np = 0;
+        if (w.d[i].objType == OBJ_NONE || w.d[i].response != RESP_DYNAMIC || w.numPlanes < 1) continue;
+        if (collide_hull_plane(hulls[i], w.planes[0].n, w.planes[0].d, raw))
+            manifold_from_raw(w, ground[i], i, -1, OBJ_PLANE, raw, true);
+    }
+    for (int k = 0; k < nsc; ++k) {
+        sc[k].np = 0;
+        int i = scBody[k], st = scStatic[k];
+        if (st >= kMaxWalls) {
+            const PlaneS &pl = w.planes[st - kMaxWalls];
+            if (collide_hull_plane(hulls[i], pl.n, pl.d, raw)) manifold_from_raw(w, sc[k], i, -1, OBJ_PLANE, raw, true);
+        } else {
+            Hull hw; hull_from_wall(hw, w.walls[st]);
+            if (collide_hulls(hulls[i], hw, raw)) manifold_from_raw(w, sc[k], i, -1, OBJ_WALL, raw);
+        }
+    }
+
+    // --- position solve: joints, body-body in pair order, then each body's static manifolds
     for (int a = 0; a < kMaxAgents; ++a) if (w.agentActive[a]) solve_grab_joint(w, a);
-    for (int k = 0; k < ndd; ++k) solve_manifold_positions(w, dd[k]);
-    for (int k = 0; k < nsm; ++k) solve_manifold_positions(w, sm[k]);
+    for (int k = 0; k < ndd; ++k) if (dd[k].np > 0) solve_manifold_positions(w, dd[k]);
+    for (int i = 0; i < kNumDSlots; ++i) {
+        if (ground[i].np > 0) solve_manifold_positions(w, ground[i]);
+        for (int k = 0; k < nsc; ++k) if (scBody[k] == i && sc[k].np > 0) solve_manifold_positions(w, sc[k]);
+    }
 
     for (int i = 0; i < kNumDSlots; ++i) derive_velocity(w.d[i]);
 
-    for (int k = 0; k < ndd; ++k) solve_manifold_velocities(w, dd[k]);
-    for (int k = 0; k < nsm; ++k) solve_manifold_velocities(w, sm[k]);
-    (void)sFirst;
+    for (int k = 0; k < ndd; ++k) if (dd[k].np > 0) solve_manifold_velocities(w, dd[k]);
+    for (int i = 0; i < kNumDSlots; ++i) {
+        if (ground[i].np > 0) solve_manifold_velocities(w, ground[i]);
+        for (int k = 0; k < nsc; ++k) if (scBody[k] == i && sc[k].np > 0) solve_manifold_velocities(w, sc[k]);
+    }
 }
 
 // ----------------------------------------------------------------------------------------

@@ -1,0 +1,113 @@
+"""Developer tool: run the HIP simulator and the CPU oracle side by side and report the first
+step/tensor where they differ (bitwise).  Usage:
+    python tools/parity_run.py [--worlds 64] [--steps 50] [--flags 0] [--seed 0] [--hiders 2 --seekers 2]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "marl-hideandseek_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import gpu_hideseek  # noqa: E402
+import hs_ref  # noqa: E402
+
+NAMES = ["reset", "prep_counter", "action", "self_data", "self_type", "self_mask", "agent_data", "box_data",
+         "ramp_data", "visible_agents_mask", "visible_boxes_mask", "visible_ramps_mask", "lidar", "seed",
+         "reward", "done", "global_positions", "episode_result"]
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worlds", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--hiders", type=int, default=2)
+    ap.add_argument("--seekers", type=int, default=2)
+    ap.add_argument("--level", type=int, default=0, help="debug level for all worlds (0 = training)")
+    ap.add_argument("--act", default="bench", choices=["bench", "full", "none"])
+    ap.add_argument("--stop", action="store_true", help="stop at first mismatch")
+    a = ap.parse_args()
+
+    import torch
+    N = a.worlds
+    ref = hs_ref.RefSim(N, sim_flags=a.flags, rand_seed=a.seed, min_hiders=a.hiders, max_hiders=a.hiders,
+                        min_seekers=a.seekers, max_seekers=a.seekers, threads=8)
+    sim = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=N, sim_flags=a.flags,
+        rand_seed=a.seed, min_hiders=a.hiders, max_hiders=a.hiders, min_seekers=a.seekers,
+        max_seekers=a.seekers, num_pbt_policies=1)
+    gt = {n: getattr(sim, ("episode_result" if n == "episode_result" else n) + "_tensor")().to_torch() for n in NAMES}
+    if a.level:
+        ref.tensor("reset")[:] = a.level
+        gt["reset"][:] = a.level
+    ref.init()
+    sim.init()
+    rng = np.random.default_rng(1234)
+    A = ref.A
+    nbad = 0
+
+    def compare(tag):
+        nonlocal nbad
+        bad = []
+        for n in NAMES:
+            g = gt[n].cpu().numpy().reshape(ref.tensor(n).shape)
+            r = ref.tensor(n)
+            if not np.array_equal(bits(g), bits(r)):
+                idx = np.argwhere(bits(g) != bits(r))
+                bad.append((n, len(idx), idx[0].tolist(), g[tuple(idx[0])], r[tuple(idx[0])]))
+        gb, gm = sim.debug_bodies()
+        rb, rm = ref.bodies()
+        if not np.array_equal(gm, rm):
+            idx = np.argwhere(gm != rm)
+            bad.append(("body_meta", len(idx), idx[0].tolist(), gm[tuple(idx[0])], rm[tuple(idx[0])]))
+        if not np.array_equal(bits(gb), bits(rb)):
+            idx = np.argwhere(bits(gb) != bits(rb))
+            bad.append(("bodies", len(idx), idx[0].tolist(), gb[tuple(idx[0])], rb[tuple(idx[0])]))
+        gw, gi = sim.debug_walls()
+        rw, ri = ref.walls()
+        if not np.array_equal(gi, ri):
+            idx = np.argwhere(gi != ri)
+            bad.append(("world_info", len(idx), idx[0].tolist(), gi[tuple(idx[0])], ri[tuple(idx[0])]))
+        if not np.array_equal(bits(gw), bits(rw)):
+            idx = np.argwhere(bits(gw) != bits(rw))
+            bad.append(("walls", len(idx), idx[0].tolist(), gw[tuple(idx[0])], rw[tuple(idx[0])]))
+        if bad:
+            nbad += 1
+            print(f"[{tag}] MISMATCH:")
+            for b in bad:
+                print("   ", b)
+        return not bad
+
+    ok = compare("init")
+    for s in range(a.steps):
+        if a.act != "none":
+            if a.act == "bench":
+                act = np.zeros((N * A, 5), np.int32)
+                act[:] = ref.tensor("action")
+                act[:, 0:2] = rng.integers(-5, 5, size=(N * A, 2))
+            else:
+                act = np.stack([rng.integers(0, 11, N * A), rng.integers(0, 11, N * A), rng.integers(0, 11, N * A),
+                                rng.integers(0, 2, N * A), rng.integers(0, 2, N * A)], axis=1).astype(np.int32)
+            ref.tensor("action")[:] = act
+            gt["action"].copy_(torch.from_numpy(act).to(gt["action"].device))
+        ref.step()
+        sim.step()
+        ok = compare(f"step {s}")
+        if not ok and a.stop:
+            break
+    print(f"done: {a.steps} steps, {N} worlds, mismatching checkpoints: {nbad}")
+    return 1 if nbad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
