@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: world-steps/s of Manager.step() at 16 000 worlds per GPU.
+
+Mirrors scripts/benchmark.py:67-92 of the reference: 5 untimed warm-up steps, then K timed
+iterations of `sim.step()` + `torch.randint(-5, 5)` into action columns 0-1, synthetic inputs
+resident in HBM.  One process per GPU (torch.distributed / RCCL only for the barrier and the
+max-over-ranks reduction — worlds are independent, there is no collective on the step path);
+rank r simulates global worlds [r*16000, (r+1)*16000) (weak scaling).
+
+Prints ONE JSON line (rank 0) with the bench contract fields plus
+  "roofline":     dominant kernel vs the HBM roofline (algorithmic bytes / HIP-event kernel time)
+  "cpu_baseline": the CPU oracle (own restatement, NOT the Madrona CPU backend) on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "marl-hideandseek_amd"))
+
+WORLDS_PER_GPU = 16000
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(sim, A, kernel):
+    """SURVEY §8(d) per-world-step bytes, summed over the actual worlds of this shard.
+    physics: 2*56*D + 16*S + 2*64 + 2*72*J + 2*20*A ; observe: 1268*A + 144 (+ reads of 56*D + 16*S)."""
+    import numpy as np
+    _, meta = sim.debug_bodies()
+    _, info = sim.debug_walls()
+    D = (meta[:, :, 0] >= 0).sum(axis=1).astype(np.float64)
+    S = info[:, 0].astype(np.float64)
+    n = float(len(D))
+    if kernel == "physics":
+        per_world = 2 * 56 * D + 16 * S + 2 * 64 + 2 * 20 * A
+    elif kernel == "observe":
+        per_world = 56 * D + 16 * S + 64 + (1268 * A + 144)
+    else:
+        per_world = 0 * D + 64
+    return float(per_world.sum()), float(per_world.sum() / n)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle timed on the host cores over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import hs_ref
+    hs_ref.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)      # a one-GPU box's CPU share is 16 cores
+    nworlds = 2000
+    ref = hs_ref.RefSim(nworlds, sim_flags=0, rand_seed=0, threads=cores)
+    ref.init()
+    rng = np.random.default_rng(0)
+    act = ref.tensor("action")
+    for _ in range(2):
+        ref.step()
+    t0 = time.time()
+    steps = 0
+    while True:
+        ref.step()
+        act[:, 0:2] = rng.integers(-5, 5, size=(act.shape[0], 2))
+        steps += 1
+        if time.time() - t0 > seconds_budget or steps >= 480:
+            break
+    dt = time.time() - t0
+    return {"value": nworlds * steps / dt, "unit": "world-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{nworlds} worlds x {steps} steps (scripts/cpu_benchmark.py args), own CPU restatement "
+                      f"(oracle/), {cores} threads over worlds; not the Madrona CPU backend"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1920)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--worlds-per-gpu", type=int, default=WORLDS_PER_GPU)
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import gpu_hideseek
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the HIP path is the only execution path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    N = args.worlds_per_gpu
+    torch.manual_seed(rank)
+    sim = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=local_rank, num_worlds=N, sim_flags=args.flags,
+        rand_seed=0, min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1,
+        world_offset=rank * N)
+    sim.init()
+    A = sim.agents_per_world
+    actions = sim.action_tensor().to_torch()
+    move = actions[..., 0:2]
+    move.copy_(torch.zeros_like(move))
+    dev = actions.device
+
+    def one_step():
+        sim.step()
+        torch.randint(-5, 5, move.shape, out=move, dtype=torch.int32, device=dev)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.set_profiling(True)
+    kms = {"physics": 0.0, "reset": 0.0, "observe": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        k = sim.last_step_kernel_ms()
+        for n in kms:
+            kms[n] += k[n]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel and its roofline position (HIP events on the launch stream, hs_step)
+    dom = max(kms, key=lambda n: kms[n])
+    avg_ms = kms[dom] / max(args.steps, 1)
+    total_bytes, per_world = algorithmic_bytes(sim, A, dom)
+    achieved = total_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_world_step": per_world,
+                "kernel_ms_per_step": {n: kms[n] / max(args.steps, 1) for n in kms}}
+
+    if rank == 0:
+        total_worlds = N * world_size
+        out = {
+            "metric": "world-steps/sec (agent-steps/sec derived) at 16K worlds, 1/2/4/8 GPU",
+            "value": total_worlds * args.steps / dt,
+            "unit": "world-steps/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N} worlds/GPU x {args.steps} steps, 2 hiders + 2 seekers, sim_flags={args.flags}, "
+                                   "rand_seed=0, random move actions in [-5,4] each step (scripts/benchmark.py args)",
+                       "worlds_per_gpu": N, "total_worlds": total_worlds, "agents_per_world": A,
+                       "sharding": "contiguous world ranges per rank, no collective on the step path"},
+            "agent_steps_per_sec": total_worlds * A * args.steps / dt,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    del sim
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""Drop-in boundary on the GPU: the tensor contract of src/mgr.cpp:1062-1331 and the call sequence
+of scripts/benchmark.py (restated here — the reference tree does not exist on the GPU box)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(n=32, **kw):
+    import gpu_hideseek
+    args = dict(exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=n, sim_flags=0, rand_seed=0,
+                min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+    args.update(kw)
+    return gpu_hideseek.HideAndSeekSimulator(**args)
+
+
+def test_tensor_shapes_dtypes_and_device():
+    import torch
+    N, A = 32, 4
+    sim = _sim(N, enable_batch_renderer=True, batch_render_width=64, batch_render_height=64)
+    sim.init()
+    R = N * A
+    expect = {
+        "reset": ((N, 1), torch.int32), "done": ((R, 1), torch.int32), "prep_counter": ((R, 1), torch.int32),
+        "action": ((R, 5), torch.int32), "reward": ((R, 1), torch.float32), "self_data": ((R, 13), torch.float32),
+        "self_type": ((R, 1), torch.int32), "self_mask": ((R, 1), torch.float32),
+        "agent_data": ((R, 5, 14), torch.float32), "box_data": ((R, 9, 17), torch.float32),
+        "ramp_data": ((R, 2, 14), torch.float32), "visible_agents_mask": ((R, 5, 1), torch.float32),
+        "visible_boxes_mask": ((R, 9, 1), torch.float32), "visible_ramps_mask": ((R, 2, 1), torch.float32),
+        "lidar": ((R, 30), torch.float32), "seed": ((R, 2), torch.int32),
+        "global_positions": ((N, 17, 2), torch.float32), "rgb": ((R, 64, 64, 4), torch.uint8),
+        "depth": ((R, 64, 64, 1), torch.float32), "episode_result": ((N, 2), torch.float32),
+        "policy_assignments": ((R, 1), torch.int32), "agent_mask": ((R, 1), torch.float32),
+    }
+    for name, (shape, dt) in expect.items():
+        t = getattr(sim, name + "_tensor")().to_torch()
+        assert tuple(t.shape) == shape and t.dtype == dt and t.is_cuda and t.is_contiguous(), name
+
+
+def test_tensors_alias_simulator_memory():
+    """The scripts mutate action/reset in place (benchmark.py:64-65,82-84): views must be zero-copy
+    and persistent."""
+    import torch
+    sim = _sim(16, sim_flags=8)
+    sim.init()
+    a1 = sim.action_tensor().to_torch()
+    a2 = sim.action_tensor().to_torch()
+    assert a1.data_ptr() == a2.data_ptr()
+    p0 = sim.self_data_tensor().to_torch()[:, :2].clone()
+    a1[:, 0] = 4                      # +800 N in x for every agent (ZeroAgentVelocity buckets)
+    for _ in range(5):
+        sim.step()
+        a1[:, 0] = 4
+    p1 = sim.self_data_tensor().to_torch()[:, :2]
+    hiders = sim.self_type_tensor().to_torch()[:, 0] == 1
+    assert (torch.linalg.norm(p1 - p0, dim=1)[hiders] > 0.05).float().mean() > 0.8
+    sim.set_action(0, 2, 2, 2, 0, 0)
+    assert a1[0].tolist() == [2, 2, 2, 0, 0]
+    sim.trigger_reset(3, 1)
+    assert sim.reset_tensor().to_torch()[3, 0].item() == 1
+    sim.step()
+    assert sim.reset_tensor().to_torch().sum().item() == 0      # consumed (sim.cpp:185)
+
+
+def test_benchmark_script_call_sequence():
+    """Same calls as scripts/benchmark.py:21-92 at a small world count."""
+    import torch
+    import gpu_hideseek
+    sim = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=256, sim_flags=0, rand_seed=0,
+        min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1,
+        enable_batch_renderer=True, batch_render_width=64, batch_render_height=64)
+    sim.init()
+    actions = sim.action_tensor().to_torch()
+    resets = sim.reset_tensor().to_torch()
+    assert actions.shape == (1024, 5) and resets.shape == (256, 1)
+    rgb = sim.rgb_tensor().to_torch()
+    assert rgb.shape == (1024, 64, 64, 4)
+    move = actions[..., 0:2]
+    move.copy_(torch.zeros_like(move))
+    for _ in range(5):
+        sim.step()
+    for _ in range(20):
+        sim.step()
+        torch.randint(-5, 5, move.shape, out=move, dtype=torch.int32, device=torch.device("cuda"))
+    assert torch.isfinite(sim.self_data_tensor().to_torch()).all()
+    del sim
+
+
+def test_step_async_on_a_caller_stream():
+    """Manager::gpuJAXStep analogue (mgr.cpp:1006-1022): enqueue on a caller stream, no sync inside."""
+    import torch
+    a, b = _sim(64, rand_seed=4), _sim(64, rand_seed=4)
+    a.init(); b.init()
+    strm = torch.cuda.Stream()
+    for _ in range(6):
+        a.step()
+        b.step_async(strm.cuda_stream)
+    strm.synchronize()
+    assert np.array_equal(a.debug_bodies()[0].view(np.int32), b.debug_bodies()[0].view(np.int32))
+
+
+def test_skip_observations_extension_leaves_physics_unchanged(oracle=None):
+    a, b = _sim(64, rand_seed=6), _sim(64, rand_seed=6, sim_flags=1 << 16)
+    a.init(); b.init()
+    for _ in range(20):          # inside the prep phase the observation side effect cannot matter
+        a.step(); b.step()
+    assert np.array_equal(a.debug_bodies()[0].view(np.int32), b.debug_bodies()[0].view(np.int32))
+    assert b.lidar_tensor().to_torch().abs().sum().item() == 0
