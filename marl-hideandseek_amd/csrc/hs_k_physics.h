@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
     const bool wok = w < N;
     PhysWorld &pw = sh[grp];
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
+    // developer-only timing ablations (results are wrong when set)
+    const bool dbg_no_sat = S.flags & (1u << 24), dbg_no_dd = S.flags & (1u << 25), dbg_no_s = S.flags & (1u << 26);
+    const bool dbg_no_cand = S.flags & (1u << 27);
 
     // ---------------- stage the world into LDS ----------------
     if (wok) {
@@ -393,7 +396,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
         __syncthreads();
         // ---------- P2: candidate pairs, compacted in pair order ----------
         unsigned dd_mask = 0; unsigned long long s_mask = 0ull; int s_planes = 0;
-        if (has_slot && present) {
+        if (has_slot && present && !dbg_no_cand) {
             const V3 lo = ld3(pw.lo[slot]), hi = ld3(pw.hi[slot]);
             for (int j = slot + 1; j < kNumDSlots; ++j) {
                 const int mj = pw.g.meta[j];
@@ -468,7 +471,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
                 RawManifold raw;
                 ManDD &m = pw.dd[k];
                 m.np = 0;
-                if (collide_hulls(ha, hb, raw)) {
+                if (!dbg_no_sat && collide_hulls(ha, hb, raw)) {
                     m.a = a; m.b = b; m.np = raw.np;
                     m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob));
                     m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
@@ -490,6 +493,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
                 RawManifold raw;
                 ManS &m = pw.sc[k];
                 m.np = 0;
+                if (dbg_no_sat) continue;
                 if (st >= kMaxWalls) {
                     const float *pl = pw.g.plane[st - kMaxWalls];
                     if (collide_hull_plane(ha, ld3(pl), pl[3], raw)) {
@@ -518,7 +522,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
         }
         __syncthreads();
         // ---------- P4: position solve ----------
-        if (wok && l == 0) {
+        if (wok && l == 0 && !dbg_no_dd) {
             for (int a = 0; a < kMaxAgents; ++a)
                 if (team_agent_active(pw.teams, a)) solve_grab_joint(pw, a);
             const int ndd = pw.ndd;
@@ -537,9 +541,10 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
         BodyS me; BodyS none;
         if (has_slot && dynamic) {
             body_load(pw, slot, me);
+            if (!dbg_no_s)
             for (int j = 0; j < 4; ++j)
                 if (j < g_np) g_lam[j] += solve_point_position<false>(me, none, g_n, hull_local_vertex(obj, g_vi[j]), V3{0.f, 0.f, 0.f}, g_off[j], g_muS);
-            const int nsc = pw.nsc;
+            const int nsc = dbg_no_s ? 0 : pw.nsc;
             for (int k = 0; k < nsc; ++k) {
                 if (pw.scBody[k] != slot) continue;
                 ManS &m = pw.sc[k];
@@ -558,7 +563,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
         }
         __syncthreads();
         // ---------- P6: velocity solve ----------
-        if (wok && l == 0) {
+        if (wok && l == 0 && !dbg_no_dd) {
             const int ndd = pw.ndd;
             for (int k = 0; k < ndd; ++k) {
                 const ManDD &m = pw.dd[k];
@@ -572,7 +577,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
             }
         }
         __syncthreads();
-        if (has_slot && dynamic) {
+        if (has_slot && dynamic && !dbg_no_s) {
             body_load(pw, slot, me);
             for (int j = 0; j < 4; ++j)
                 if (j < g_np) solve_point_velocity<false>(me, none, g_n, hull_local_vertex(obj, g_vi[j]), V3{0.f, 0.f, 0.f}, g_lam[j], g_muD);
