@@ -1,30 +1,74 @@
 // Convex narrowphase on the device: exact SAT over face normals and edge-direction cross products
 // with reference-face clipping (boxes, scaled wall boxes and the ramp wedge), and hull-vs-plane.
 // Replaces madrona::phys narrowphase (spliced in at src/sim.cpp:1162-1163; engine source absent
-// — DESIGN.md "Engine decisions").  Hull vertices of movable bodies live in LDS (written once
-// per substep by the owning lane); wall hulls are generated from (cx,cy,hx,hy) on the fly.
+// — DESIGN.md "Engine decisions").
+//
+// Nothing here touches memory except the per-lane LDS clip buffer: hull vertices are computed from
+// (centre, rotation columns, half extents) when needed, box supports are closed-form
+// (centre projection -/+ projected radius), and the hull topology tables of data/*_collision.obj
+// are bit-packed immediates instead of lookup tables.
 #pragma once
 #include "hs_dev.h"
 
 namespace hs {
 
-// ---- hull topology (data/*_collision.obj): boxes 8v/6f/12e, wedge 6v/5f/9e ----
-__constant__ int cBoxFaceIdx[6][4] = {{0, 4, 6, 2}, {1, 3, 7, 5}, {0, 1, 5, 4}, {2, 6, 7, 3}, {0, 2, 3, 1}, {4, 5, 7, 6}};
-__constant__ int cBoxEdges[12][3] = {{0, 1, 0}, {2, 3, 0}, {4, 5, 0}, {6, 7, 0}, {0, 2, 1}, {1, 3, 1},
-                                     {4, 6, 1}, {5, 7, 1}, {0, 4, 2}, {1, 5, 2}, {2, 6, 2}, {3, 7, 2}};
-__constant__ float cWedgeV[6][3] = {{1, 1, 1}, {1, 1, -1}, {1, -2, -1}, {-1, 1, 1}, {-1, 1, -1}, {-1, -2, -1}};
-__constant__ int cWedgeFaceCnt[5] = {4, 4, 4, 3, 3};
-__constant__ int cWedgeFaceIdx[5][4] = {{4, 1, 2, 5}, {4, 3, 0, 1}, {2, 0, 3, 5}, {1, 0, 2, 0}, {5, 3, 4, 0}};
-__constant__ float cWedgeFN[5][3] = {{0, 0, -1}, {0, 1, 0}, {0, -0.554700196f, 0.832050294f}, {1, 0, 0}, {-1, 0, 0}};
-__constant__ int cWedgeEdges[9][3] = {{4, 1, 0}, {2, 5, 0}, {3, 0, 0}, {1, 2, 1}, {5, 4, 1}, {4, 3, 2}, {0, 1, 2}, {2, 0, 3}, {5, 3, 3}};
-
-enum { HULL_BOX = 0, HULL_WEDGE = 1, HULL_WALL = 2 };
+enum { HULL_BOX = 0, HULL_WEDGE = 1 };
 
 struct HullRef {
     int kind;
-    const float (*v)[3];    // LDS vertices (HULL_BOX / HULL_WEDGE)
-    V3 c, ax, ay, az, e;    // centre, rotation columns, half extents
+    V3 c, ax, ay, az, e;    // centre, rotation columns, half extents (boxes)
 };
+
+// ---- packed topology ----
+// box face loops {0,4,6,2},{1,3,7,5},{0,1,5,4},{2,6,7,3},{0,2,3,1},{4,5,7,6}: 3 bits per index
+HSD int box_face_idx(int f, int k) {
+    constexpr unsigned long long t0 = (0ull) | (4ull << 3) | (6ull << 6) | (2ull << 9) |
+                                      (1ull << 12) | (3ull << 15) | (7ull << 18) | (5ull << 21) |
+                                      (0ull << 24) | (1ull << 27) | (5ull << 30) | (4ull << 33);
+    constexpr unsigned long long t1 = (2ull) | (6ull << 3) | (7ull << 6) | (3ull << 9) |
+                                      (0ull << 12) | (2ull << 15) | (3ull << 18) | (1ull << 21) |
+                                      (4ull << 24) | (5ull << 27) | (7ull << 30) | (6ull << 33);
+    const unsigned long long t = f < 3 ? t0 : t1;
+    const int ff = f < 3 ? f : f - 3;
+    return (int)((t >> (ff * 12 + k * 3)) & 7ull);
+}
+// wedge face loops {4,1,2,5},{4,3,0,1},{2,0,3,5},{1,0,2,0},{5,3,4,0}
+HSD int wedge_face_idx(int f, int k) {
+    constexpr unsigned long long t = (4ull) | (1ull << 3) | (2ull << 6) | (5ull << 9) |
+                                     (4ull << 12) | (3ull << 15) | (0ull << 18) | (1ull << 21) |
+                                     (2ull << 24) | (0ull << 27) | (3ull << 30) | (5ull << 33) |
+                                     (1ull << 36) | (0ull << 39) | (2ull << 42) | (0ull << 45) |
+                                     (5ull << 48) | (3ull << 51) | (4ull << 54) | (0ull << 57);
+    return (int)((t >> (f * 12 + k * 3)) & 7ull);
+}
+// wedge edges {4,1,0},{2,5,0},{3,0,0},{1,2,1},{5,4,1},{4,3,2},{0,1,2},{2,0,3},{5,3,3}
+HSD void wedge_edge(int e, int *v0, int *v1, int *dir) {
+    constexpr unsigned long long tv = (4ull | (1ull << 3)) | ((2ull | (5ull << 3)) << 6) | ((3ull | (0ull << 3)) << 12) |
+                                      ((1ull | (2ull << 3)) << 18) | ((5ull | (4ull << 3)) << 24) | ((4ull | (3ull << 3)) << 30) |
+                                      ((0ull | (1ull << 3)) << 36) | ((2ull | (0ull << 3)) << 42) | ((5ull | (3ull << 3)) << 48);
+    constexpr unsigned td = 0u | (0u << 2) | (0u << 4) | (1u << 6) | (1u << 8) | (2u << 10) | (2u << 12) | (3u << 14) | (3u << 16);
+    *v0 = (int)((tv >> (e * 6)) & 7ull); *v1 = (int)((tv >> (e * 6 + 3)) & 7ull); *dir = (int)((td >> (e * 2)) & 3u);
+}
+// box edges: x-direction {0,1},{2,3},{4,5},{6,7}; y {0,2},{1,3},{4,6},{5,7}; z {0,4},{1,5},{2,6},{3,7}
+HSD void box_edge(int e, int *v0, int *v1, int *dir) {
+    const int d = e >> 2, k = e & 3;
+    int a, b;
+    if (d == 0) { a = k << 1; b = a | 1; }
+    else if (d == 1) { a = (k & 1) | ((k & 2) << 1); b = a | 2; }
+    else { a = k; b = k | 4; }
+    *v0 = a; *v1 = b; *dir = d;
+}
+HSD V3 wedge_local_v(int i) {     // {1,1,1},{1,1,-1},{1,-2,-1},{-1,1,1},{-1,1,-1},{-1,-2,-1}
+    const int r = i >= 3 ? i - 3 : i;
+    return {i < 3 ? 1.f : -1.f, r == 2 ? -2.f : 1.f, r == 0 ? 1.f : -1.f};
+}
+HSD V3 wedge_local_fn(int f) {    // {0,0,-1},{0,1,0},{0,-2,3}/sqrt13,{1,0,0},{-1,0,0}
+    if (f == 0) return {0.f, 0.f, -1.f};
+    if (f == 1) return {0.f, 1.f, 0.f};
+    if (f == 2) return {0.f, -0.554700196f, 0.832050294f};
+    if (f == 3) return {1.f, 0.f, 0.f};
+    return {-1.f, 0.f, 0.f};
+}
 
 HSD int hull_nv(const HullRef &h) { return h.kind == HULL_WEDGE ? 6 : 8; }
 HSD int hull_nf(const HullRef &h) { return h.kind == HULL_WEDGE ? 5 : 6; }
@@ -32,19 +76,27 @@ HSD int hull_ned(const HullRef &h) { return h.kind == HULL_WEDGE ? 4 : 3; }
 HSD int hull_ne(const HullRef &h) { return h.kind == HULL_WEDGE ? 9 : 12; }
 
 HSD V3 hull_v(const HullRef &h, int i) {
-    if (h.kind == HULL_WALL)
-        return {h.c.x + ((i & 1) ? h.e.x : -h.e.x), h.c.y + ((i & 2) ? h.e.y : -h.e.y), h.c.z + ((i & 4) ? h.e.z : -h.e.z)};
-    return {h.v[i][0], h.v[i][1], h.v[i][2]};
+    V3 l;
+    if (h.kind == HULL_WEDGE) l = wedge_local_v(i);
+    else l = {(i & 1) ? h.e.x : -h.e.x, (i & 2) ? h.e.y : -h.e.y, (i & 4) ? h.e.z : -h.e.z};
+    return ((h.c + h.ax * l.x) + h.ay * l.y) + h.az * l.z;
 }
 HSD V3 hull_fn(const HullRef &h, int f) {
-    if (h.kind == HULL_WEDGE)
-        return (h.ax * cWedgeFN[f][0] + h.ay * cWedgeFN[f][1]) + h.az * cWedgeFN[f][2];
+    if (h.kind == HULL_WEDGE) {
+        V3 l = wedge_local_fn(f);
+        return (h.ax * l.x + h.ay * l.y) + h.az * l.z;
+    }
     V3 a = (f >> 1) == 0 ? h.ax : ((f >> 1) == 1 ? h.ay : h.az);
     return (f & 1) ? a : -a;
 }
-HSD int hull_fcnt(const HullRef &h, int f) { return h.kind == HULL_WEDGE ? cWedgeFaceCnt[f] : 4; }
-HSD int hull_fidx(const HullRef &h, int f, int k) { return h.kind == HULL_WEDGE ? cWedgeFaceIdx[f][k] : cBoxFaceIdx[f][k]; }
-HSD float hull_fd(const HullRef &h, int f, V3 fn) { return dot(fn, hull_v(h, hull_fidx(h, f, 0))); }
+HSD int hull_fcnt(const HullRef &h, int f) { return (h.kind == HULL_WEDGE && f >= 3) ? 3 : 4; }
+HSD int hull_fidx(const HullRef &h, int f, int k) { return h.kind == HULL_WEDGE ? wedge_face_idx(f, k) : box_face_idx(f, k); }
+// plane offset of face f (normal fn): closed form for boxes, first loop vertex for the wedge
+HSD float hull_fd(const HullRef &h, int f, V3 fn) {
+    if (h.kind == HULL_WEDGE) return dot(fn, hull_v(h, wedge_face_idx(f, 0)));
+    const float ei = (f >> 1) == 0 ? h.e.x : ((f >> 1) == 1 ? h.e.y : h.e.z);
+    return dot(fn, h.c) + ei;
+}
 HSD V3 hull_ed(const HullRef &h, int i) {
     if (i == 0) return h.ax;
     if (i == 1) return h.ay;
@@ -52,69 +104,61 @@ HSD V3 hull_ed(const HullRef &h, int i) {
     return (h.ax * 0.f + h.ay * 0.832050294f) + h.az * 0.554700196f;
 }
 HSD void hull_edge(const HullRef &h, int e, int *v0, int *v1, int *dir) {
-    if (h.kind == HULL_WEDGE) { *v0 = cWedgeEdges[e][0]; *v1 = cWedgeEdges[e][1]; *dir = cWedgeEdges[e][2]; }
-    else { *v0 = cBoxEdges[e][0]; *v1 = cBoxEdges[e][1]; *dir = cBoxEdges[e][2]; }
+    if (h.kind == HULL_WEDGE) wedge_edge(e, v0, v1, dir); else box_edge(e, v0, v1, dir);
 }
-// Local-frame vertex of a movable hull
 HSD V3 hull_local_vertex(int obj, int i) {
-    if (obj == OBJ_RAMP) return {cWedgeV[i][0], cWedgeV[i][1], cWedgeV[i][2]};
+    if (obj == OBJ_RAMP) return wedge_local_v(i);
     V3 e = obj_half_extents(obj);
     return {(i & 1) ? e.x : -e.x, (i & 2) ? e.y : -e.y, (i & 4) ? e.z : -e.z};
 }
 
-// Write the world-space vertices of a movable body and return its AABB.
-HSD void hull_build(int obj, V3 pos, Q rot, float (*v)[3], V3 *lo_out, V3 *hi_out) {
+HSD HullRef hull_ref_body(int obj, V3 pos, Q rot) {
     M3 m = m3_from_quat(rot);
-    V3 lo, hi;
-    if (obj == OBJ_RAMP) {
+    HullRef h;
+    h.kind = obj == OBJ_RAMP ? HULL_WEDGE : HULL_BOX;
+    h.c = pos; h.ax = m.c0; h.ay = m.c1; h.az = m.c2;
+    h.e = obj == OBJ_RAMP ? V3{1.f, 1.f, 1.f} : obj_half_extents(obj);
+    return h;
+}
+HSD HullRef hull_ref_wall(float cx, float cy, float hx, float hy) {
+    HullRef h;
+    h.kind = HULL_BOX;
+    h.c = {cx, cy, 1.25f}; h.ax = {1.f, 0.f, 0.f}; h.ay = {0.f, 1.f, 0.f}; h.az = {0.f, 0.f, 1.f};
+    h.e = {hx, hy, 1.25f};
+    return h;
+}
+// AABB of the hull's vertices
+HSD void hull_aabb(const HullRef &h, V3 *lo_out, V3 *hi_out) {
+    V3 lo = hull_v(h, 0), hi = lo;
+    const int nv = hull_nv(h);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            V3 p = ((pos + m.c0 * cWedgeV[i][0]) + m.c1 * cWedgeV[i][1]) + m.c2 * cWedgeV[i][2];
-            v[i][0] = p.x; v[i][1] = p.y; v[i][2] = p.z;
-            if (i == 0) { lo = p; hi = p; }
-            else { lo = {fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z)}; hi = {fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z)}; }
-        }
-    } else {
-        V3 e = obj_half_extents(obj);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float sx = (i & 1) ? e.x : -e.x, sy = (i & 2) ? e.y : -e.y, sz = (i & 4) ? e.z : -e.z;
-            V3 p = ((pos + m.c0 * sx) + m.c1 * sy) + m.c2 * sz;
-            v[i][0] = p.x; v[i][1] = p.y; v[i][2] = p.z;
-            if (i == 0) { lo = p; hi = p; }
-            else { lo = {fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z)}; hi = {fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z)}; }
+    for (int i = 1; i < 8; ++i) {
+        if (i < nv) {
+            V3 p = hull_v(h, i);
+            lo = {fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z)};
+            hi = {fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z)};
         }
     }
     *lo_out = lo; *hi_out = hi;
 }
 
-HSD HullRef hull_ref_body(int obj, V3 pos, Q rot, const float (*v)[3]) {
-    M3 m = m3_from_quat(rot);
-    HullRef h;
-    h.kind = obj == OBJ_RAMP ? HULL_WEDGE : HULL_BOX;
-    h.v = v; h.c = pos; h.ax = m.c0; h.ay = m.c1; h.az = m.c2; h.e = obj_half_extents(obj);
-    return h;
-}
-HSD HullRef hull_ref_wall(float cx, float cy, float hx, float hy) {
-    HullRef h;
-    h.kind = HULL_WALL; h.v = nullptr;
-    h.c = {cx, cy, 1.25f}; h.ax = {1.f, 0.f, 0.f}; h.ay = {0.f, 1.f, 0.f}; h.az = {0.f, 0.f, 1.f};
-    h.e = {hx, hy, 1.25f};
-    return h;
-}
-
 struct RawManifold { V3 n; int np; V3 pA[4]; V3 pB[4]; int vidx[4]; };
 
+HSD float box_radius(const HullRef &h, V3 n) {
+    return (fabsf(dot(n, h.ax)) * h.e.x + fabsf(dot(n, h.ay)) * h.e.y) + fabsf(dot(n, h.az)) * h.e.z;
+}
 HSD float support_min(const HullRef &h, V3 n) {
-    const int nv = hull_nv(h);
+    if (h.kind == HULL_BOX) return dot(n, h.c) - box_radius(h, n);
     float s = dot(n, hull_v(h, 0));
-    for (int i = 1; i < nv; ++i) s = fminf(s, dot(n, hull_v(h, i)));
+#pragma unroll
+    for (int i = 1; i < 6; ++i) s = fminf(s, dot(n, hull_v(h, i)));
     return s;
 }
 HSD float support_max(const HullRef &h, V3 n) {
-    const int nv = hull_nv(h);
+    if (h.kind == HULL_BOX) return dot(n, h.c) + box_radius(h, n);
     float s = dot(n, hull_v(h, 0));
-    for (int i = 1; i < nv; ++i) s = fmaxf(s, dot(n, hull_v(h, i)));
+#pragma unroll
+    for (int i = 1; i < 6; ++i) s = fmaxf(s, dot(n, hull_v(h, i)));
     return s;
 }
 
@@ -122,7 +166,9 @@ HSD float support_max(const HullRef &h, V3 n) {
 HSD bool collide_hull_plane(const HullRef &A, V3 pn, float pd, RawManifold &m) {
     int np = 0; float depth[4] = {0.f, 0.f, 0.f, 0.f};
     const int nv = hull_nv(A);
-    for (int i = 0; i < nv; ++i) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= nv) continue;
         V3 v = hull_v(A, i);
         float dist = dot(pn, v) - pd;
         if (!(dist < 0.f)) continue;
@@ -158,63 +204,86 @@ HSD void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3 *c1, V3 *c2) {
     *c1 = p1 + d1 * s; *c2 = p2 + d2 * t;
 }
 
+// per-lane LDS scratch for polygon clipping: two ping-pong polygons of up to 8 vertices
+struct ClipBuf { float p[2][8][3]; };
+HSD V3 cb_get(const ClipBuf &b, int w, int i) { return {b.p[w][i][0], b.p[w][i][1], b.p[w][i][2]}; }
+HSD void cb_set(ClipBuf &b, int w, int i, V3 v) { b.p[w][i][0] = v.x; b.p[w][i][1] = v.y; b.p[w][i][2] = v.z; }
+
 // Clip the incident face of I against the side planes of reference face fr of R; keep points on
-// or below the reference plane; reduce to <= 4.
-HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, V3 *pInc, float *dist_out) {
+// or below the reference plane; reduce to <= 4.  Returns the count; pInc/dist_out have 4 slots.
+HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, ClipBuf &cb, V3 *pInc, float *dist_out) {
     const float dr = hull_fd(R, fr, nr);
     const int inf = hull_nf(I);
     int fi = 0; float best = dot(nr, hull_fn(I, 0));
     for (int f = 1; f < inf; ++f) { float d = dot(nr, hull_fn(I, f)); if (d < best) { best = d; fi = f; } }
-    V3 poly[8], tmp[8]; int n = hull_fcnt(I, fi);
-    for (int k = 0; k < n; ++k) poly[k] = hull_v(I, hull_fidx(I, fi, k));
+    int n = hull_fcnt(I, fi);
+    int cur_buf = 0;
+    for (int k = 0; k < n; ++k) cb_set(cb, 0, k, hull_v(I, hull_fidx(I, fi, k)));
     const int rc = hull_fcnt(R, fr);
     for (int k = 0; k < rc && n > 0; ++k) {
-        V3 v0 = hull_v(R, hull_fidx(R, fr, k)), v1 = hull_v(R, hull_fidx(R, fr, (k + 1) % rc));
+        const int k1 = (k + 1 == rc) ? 0 : k + 1;
+        V3 v0 = hull_v(R, hull_fidx(R, fr, k)), v1 = hull_v(R, hull_fidx(R, fr, k1));
         V3 s = cross(v1 - v0, nr);
         int m = 0;
-        V3 prev = poly[n - 1]; float dprev = dot(s, prev - v0);
+        const int src = cur_buf, dst = cur_buf ^ 1;
+        V3 prev = cb_get(cb, src, n - 1); float dprev = dot(s, prev - v0);
         for (int i = 0; i < n; ++i) {
-            V3 cur = poly[i]; float dcur = dot(s, cur - v0);
+            V3 cur = cb_get(cb, src, i); float dcur = dot(s, cur - v0);
             bool in_prev = dprev <= 0.f, in_cur = dcur <= 0.f;
             if (in_prev != in_cur) {
                 float t = dprev / (dprev - dcur);
-                if (m < 8) tmp[m++] = prev + (cur - prev) * t;
+                if (m < 8) { cb_set(cb, dst, m, prev + (cur - prev) * t); m++; }
             }
-            if (in_cur) { if (m < 8) tmp[m++] = cur; }
+            if (in_cur) { if (m < 8) { cb_set(cb, dst, m, cur); m++; } }
             prev = cur; dprev = dcur;
         }
         n = m;
-        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+        cur_buf = dst;
     }
-    V3 pts[8]; float dist[8]; int c = 0;
+    // compact points on or below the reference plane into the other buffer
+    const int src = cur_buf, pts = cur_buf ^ 1;
+    int c = 0;
     for (int i = 0; i < n; ++i) {
-        float d = dot(nr, poly[i]) - dr;
-        if (d <= 0.f) { pts[c] = poly[i]; dist[c] = d; c++; }
+        V3 p = cb_get(cb, src, i);
+        float d = dot(nr, p) - dr;
+        if (d <= 0.f) { cb_set(cb, pts, c, p); c++; }
     }
+#define HS_PT(i) cb_get(cb, pts, (i))
+#define HS_DIST(i) (dot(nr, HS_PT(i)) - dr)
     if (c <= 4) {
-        for (int i = 0; i < c; ++i) { pInc[i] = pts[i]; dist_out[i] = dist[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < c) { pInc[i] = HS_PT(i); dist_out[i] = HS_DIST(i); }
         return c;
     }
-    int i0 = 0; for (int i = 1; i < c; ++i) if (dist[i] < dist[i0]) i0 = i;
+    int i0 = 0; float d0 = HS_DIST(0);
+    for (int i = 1; i < c; ++i) { float d = HS_DIST(i); if (d < d0) { d0 = d; i0 = i; } }
+    const V3 p0 = HS_PT(i0);
     int i1 = -1; float bd = -1.f;
-    for (int i = 0; i < c; ++i) { if (i == i0) continue; float d2 = len2(pts[i] - pts[i0]); if (d2 > bd) { bd = d2; i1 = i; } }
+    for (int i = 0; i < c; ++i) { if (i == i0) continue; float d2 = len2(HS_PT(i) - p0); if (d2 > bd) { bd = d2; i1 = i; } }
+    const V3 p1 = HS_PT(i1);
     int i2 = -1, i3 = -1; float amax = 0.f, amin = 0.f;
     for (int i = 0; i < c; ++i) {
         if (i == i0 || i == i1) continue;
-        float ar = dot(cross(pts[i0] - pts[i], pts[i1] - pts[i]), nr);
+        V3 p = HS_PT(i);
+        float ar = dot(cross(p0 - p, p1 - p), nr);
         if (i2 < 0 || ar > amax) { amax = ar; i2 = i; }
     }
     for (int i = 0; i < c; ++i) {
         if (i == i0 || i == i1 || i == i2) continue;
-        float ar = dot(cross(pts[i0] - pts[i], pts[i1] - pts[i]), nr);
+        V3 p = HS_PT(i);
+        float ar = dot(cross(p0 - p, p1 - p), nr);
         if (i3 < 0 || ar < amin) { amin = ar; i3 = i; }
     }
-    const int sel[4] = {i0, i1, i2, i3};
-    for (int k = 0; k < 4; ++k) { pInc[k] = pts[sel[k]]; dist_out[k] = dist[sel[k]]; }
+    pInc[0] = p0; dist_out[0] = HS_DIST(i0);
+    pInc[1] = p1; dist_out[1] = HS_DIST(i1);
+    pInc[2] = HS_PT(i2); dist_out[2] = HS_DIST(i2);
+    pInc[3] = HS_PT(i3); dist_out[3] = HS_DIST(i3);
+#undef HS_PT
+#undef HS_DIST
     return 4;
 }
 
-HSD bool collide_hulls(const HullRef &A, const HullRef &B, RawManifold &m) {
+HSD bool collide_hulls(const HullRef &A, const HullRef &B, ClipBuf &cb, RawManifold &m) {
     float bestA = 0.f; int fa = -1;
     const int anf = hull_nf(A), bnf = hull_nf(B);
     for (int f = 0; f < anf; ++f) {
@@ -272,16 +341,18 @@ HSD bool collide_hulls(const HullRef &A, const HullRef &B, RawManifold &m) {
     V3 pinc[4]; float dist[4];
     if (bestB > 0.98f * bestA + 0.00125f) {
         V3 nr = hull_fn(B, fb);
-        int c = clip_face_contact(B, fb, nr, A, pinc, dist);
+        int c = clip_face_contact(B, fb, nr, A, cb, pinc, dist);
         if (c == 0) return false;
         m.n = -nr; m.np = c;
-        for (int i = 0; i < c; ++i) { m.pA[i] = pinc[i]; m.pB[i] = pinc[i] - nr * dist[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < c) { m.pA[i] = pinc[i]; m.pB[i] = pinc[i] - nr * dist[i]; }
     } else {
         V3 nr = hull_fn(A, fa);
-        int c = clip_face_contact(A, fa, nr, B, pinc, dist);
+        int c = clip_face_contact(A, fa, nr, B, cb, pinc, dist);
         if (c == 0) return false;
         m.n = nr; m.np = c;
-        for (int i = 0; i < c; ++i) { m.pB[i] = pinc[i]; m.pA[i] = pinc[i] - nr * dist[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < c) { m.pB[i] = pinc[i]; m.pA[i] = pinc[i] - nr * dist[i]; }
     }
     return true;
 }

@@ -29,7 +29,6 @@ struct PhysWorld {
     float lin[kNumDSlots][3], ang[kNumDSlots][3];
     float ppos[kNumDSlots][3], prot[kNumDSlots][4];
     float lo[kNumDSlots][3], hi[kNumDSlots][3];
-    float hv[kNumDSlots][8][3];
     int cnt[32];
     int ndd, nsc;
     unsigned char ddA[kMaxDDCand], ddB[kMaxDDCand], scBody[kMaxSCand], scStatic[kMaxSCand];
@@ -274,7 +273,9 @@ HSD void action_system(PhysWorld &pw, int A_) {
 template <int G>
 __global__ void __launch_bounds__(64) k_physics(SimState S) {
     constexpr int W = 64 / G;
+    constexpr int SATL = 8;                 // lanes per group that run convex tests
     __shared__ PhysWorld sh[W];
+    __shared__ ClipBuf clipbuf[W * SATL];
     const int lane = threadIdx.x;
     const int grp = lane / G, l = lane % G;
     const int w = blockIdx.x * W + grp;
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
             }
             if (present) {
                 V3 lo, hi;
-                hull_build(obj, pos, rot, pw.hv[slot], &lo, &hi);
+                hull_aabb(hull_ref_body(obj, pos, rot), &lo, &hi);
                 st3(pw.lo[slot], lo); st3(pw.hi[slot], hi);
             }
         }
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
         // ---------- P3: narrowphase, spread over the lanes of the group ----------
         g_np = 0;
         if (has_slot && dynamic && pw.g.numPlanes >= 1) {
-            HullRef hb = hull_ref_body(obj, ld3(pw.g.pos[slot]), ld4(pw.g.rot[slot]), pw.hv[slot]);
+            HullRef hb = hull_ref_body(obj, ld3(pw.g.pos[slot]), ld4(pw.g.rot[slot]));
             RawManifold raw;
             const V3 pn = ld3(pw.g.plane[0]);
             if (collide_hull_plane(hb, pn, pw.g.plane[0][3], raw)) {
@@ -459,63 +460,68 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
                 for (int j = 0; j < 4; ++j) { g_vi[j] = raw.vidx[j]; g_off[j] = dot(raw.pB[j], raw.n); g_lam[j] = 0.f; }
             }
         }
-        if (wok) {
-            const int ndd = pw.ndd, nsc = pw.nsc;
-            for (int k = l; k < ndd; k += G) {
-                const int a = pw.ddA[k], b = pw.ddB[k];
-                const int oa = meta_obj(pw.g.meta[a]), ob = meta_obj(pw.g.meta[b]);
-                const V3 pa = ld3(pw.g.pos[a]), pb = ld3(pw.g.pos[b]);
-                const Q qa = ld4(pw.g.rot[a]), qb = ld4(pw.g.rot[b]);
-                HullRef ha = hull_ref_body(oa, pa, qa, pw.hv[a]);
-                HullRef hb = hull_ref_body(ob, pb, qb, pw.hv[b]);
-                RawManifold raw;
-                ManDD &m = pw.dd[k];
-                m.np = 0;
-                if (!dbg_no_sat && collide_hulls(ha, hb, raw)) {
-                    m.a = a; m.b = b; m.np = raw.np;
-                    m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob));
-                    m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
-                    st3(m.n, raw.n);
-                    const Q qai = qinv(qa), qbi = qinv(qb);
-                    for (int j = 0; j < raw.np; ++j) {
-                        st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
-                        st3(m.rB[j], qrot(qbi, raw.pB[j] - pb));
-                        m.lam[j] = 0.f;
-                    }
-                }
-            }
-            for (int k = l; k < nsc; k += G) {
-                const int a = pw.scBody[k], st = pw.scStatic[k];
+        if (wok && l < SATL) {
+            // one work list: body-body pairs, then body-static pairs; both run the same convex test
+            const int ndd = pw.ndd, ntot = pw.ndd + pw.nsc;
+            ClipBuf &cb = clipbuf[grp * SATL + l];
+            for (int k = l; k < ntot; k += SATL) {
+                const bool isdd = k < ndd;
+                const int kk = isdd ? k : k - ndd;
+                const int a = isdd ? pw.ddA[kk] : pw.scBody[kk];
+                const int bsel = isdd ? pw.ddB[kk] : pw.scStatic[kk];
                 const int oa = meta_obj(pw.g.meta[a]);
                 const V3 pa = ld3(pw.g.pos[a]);
                 const Q qa = ld4(pw.g.rot[a]);
-                HullRef ha = hull_ref_body(oa, pa, qa, pw.hv[a]);
+                const HullRef ha = hull_ref_body(oa, pa, qa);
                 RawManifold raw;
-                ManS &m = pw.sc[k];
-                m.np = 0;
+                if (isdd) pw.dd[kk].np = 0; else pw.sc[kk].np = 0;
                 if (dbg_no_sat) continue;
-                if (st >= kMaxWalls) {
-                    const float *pl = pw.g.plane[st - kMaxWalls];
+                if (!isdd && bsel >= kMaxWalls) {
+                    ManS &m = pw.sc[kk];
+                    const float *pl = pw.g.plane[bsel - kMaxWalls];
                     if (collide_hull_plane(ha, ld3(pl), pl[3], raw)) {
                         m.np = raw.np; st3(m.n, raw.n);
                         m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
                         m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
-                        for (int j = 0; j < raw.np; ++j) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (j < raw.np) {
                             st3(m.rA[j], hull_local_vertex(oa, raw.vidx[j]));
                             m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
                         }
                     }
+                    continue;
+                }
+                int ob; V3 pb = {0.f, 0.f, 0.f}; Q qb = {1.f, 0.f, 0.f, 0.f};
+                HullRef hb;
+                if (isdd) {
+                    ob = meta_obj(pw.g.meta[bsel]); pb = ld3(pw.g.pos[bsel]); qb = ld4(pw.g.rot[bsel]);
+                    hb = hull_ref_body(ob, pb, qb);
                 } else {
-                    HullRef hw = hull_ref_wall(pw.g.wall[st][0], pw.g.wall[st][1], pw.g.wall[st][2], pw.g.wall[st][3]);
-                    if (collide_hulls(ha, hw, raw)) {
-                        m.np = raw.np; st3(m.n, raw.n);
-                        m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_WALL));
-                        m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_WALL));
-                        const Q qai = qinv(qa);
-                        for (int j = 0; j < raw.np; ++j) {
-                            st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
-                            m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
-                        }
+                    ob = OBJ_WALL;
+                    hb = hull_ref_wall(pw.g.wall[bsel][0], pw.g.wall[bsel][1], pw.g.wall[bsel][2], pw.g.wall[bsel][3]);
+                }
+                if (!collide_hulls(ha, hb, cb, raw)) continue;
+                const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
+                const Q qai = qinv(qa);
+                if (isdd) {
+                    ManDD &m = pw.dd[kk];
+                    m.a = a; m.b = bsel; m.np = raw.np; m.muS = muS; m.muD = muD;
+                    st3(m.n, raw.n);
+                    const Q qbi = qinv(qb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (j < raw.np) {
+                        st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
+                        st3(m.rB[j], qrot(qbi, raw.pB[j] - pb));
+                        m.lam[j] = 0.f;
+                    }
+                } else {
+                    ManS &m = pw.sc[kk];
+                    m.np = raw.np; m.muS = muS; m.muD = muD;
+                    st3(m.n, raw.n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (j < raw.np) {
+                        st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
+                        m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
                     }
                 }
             }

@@ -71,6 +71,7 @@ struct Hull {
     int e0[12], e1[12], edir[12];
     V3 center;
     V3 lo, hi;
+    bool is_box; V3 ax, ay, az, e;   // boxes: rotation columns and half extents (closed-form supports)
 };
 
 static const int kBoxFaceIdx[6][4] = {
@@ -89,7 +90,10 @@ static const int kWedgeEdges[9][3] = {
 static const float kWedgeSlant[3] = {0.f, 0.832050294f, 0.554700196f};   // (0,3,2)/sqrt(13)
 
 static inline void hull_finish(Hull &h) {
-    for (int f = 0; f < h.nf; ++f) h.fd[f] = dot(h.fn[f], h.v[h.fidx[f][0]]);
+    for (int f = 0; f < h.nf; ++f) {
+        if (h.is_box) { float ei = (f >> 1) == 0 ? h.e.x : ((f >> 1) == 1 ? h.e.y : h.e.z); h.fd[f] = dot(h.fn[f], h.center) + ei; }
+        else h.fd[f] = dot(h.fn[f], h.v[h.fidx[f][0]]);
+    }
     V3 lo = h.v[0], hi = h.v[0];
     for (int i = 1; i < h.nv; ++i) {
         V3 p = h.v[i];
@@ -101,7 +105,7 @@ static inline void hull_finish(Hull &h) {
 
 static inline void hull_box(Hull &h, V3 c, V3 ax, V3 ay, V3 az, V3 e) {
     h.nv = 8; h.nf = 6; h.ned = 3; h.ne = 12;
-    h.center = c;
+    h.center = c; h.is_box = true; h.ax = ax; h.ay = ay; h.az = az; h.e = e;
     for (int i = 0; i < 8; ++i) {
         float sx = (i & 1) ? e.x : -e.x, sy = (i & 2) ? e.y : -e.y, sz = (i & 4) ? e.z : -e.z;
         h.v[i] = ((c + ax * sx) + ay * sy) + az * sz;
@@ -115,7 +119,7 @@ static inline void hull_box(Hull &h, V3 c, V3 ax, V3 ay, V3 az, V3 e) {
 
 static inline void hull_wedge(Hull &h, V3 c, const M3 &m) {
     h.nv = 6; h.nf = 5; h.ned = 4; h.ne = 9;
-    h.center = c;
+    h.center = c; h.is_box = false; h.ax = m.c0; h.ay = m.c1; h.az = m.c2; h.e = {1.f, 1.f, 1.f};
     for (int i = 0; i < 6; ++i)
         h.v[i] = ((c + m.c0 * kWedgeV[i][0]) + m.c1 * kWedgeV[i][1]) + m.c2 * kWedgeV[i][2];
     for (int f = 0; f < 5; ++f) {
@@ -192,12 +196,18 @@ static inline bool collide_hull_plane(const Hull &A, V3 pn, float pd, RawManifol
     return np > 0;
 }
 
+// Boxes: centre projection -/+ projected radius; the wedge walks its 6 vertices.
+static inline float box_radius(const Hull &h, V3 n) {
+    return (fabsf(dot(n, h.ax)) * h.e.x + fabsf(dot(n, h.ay)) * h.e.y) + fabsf(dot(n, h.az)) * h.e.z;
+}
 static inline float support_min(const Hull &h, V3 n) {
+    if (h.is_box) return dot(n, h.center) - box_radius(h, n);
     float s = dot(n, h.v[0]);
     for (int i = 1; i < h.nv; ++i) s = fminf(s, dot(n, h.v[i]));
     return s;
 }
 static inline float support_max(const Hull &h, V3 n) {
+    if (h.is_box) return dot(n, h.center) + box_radius(h, n);
     float s = dot(n, h.v[0]);
     for (int i = 1; i < h.nv; ++i) s = fmaxf(s, dot(n, h.v[i]));
     return s;
