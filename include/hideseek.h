@@ -136,6 +136,9 @@ int32_t hs_debug_dump_walls(hs_sim *sim, float *walls, int32_t *info);
 int32_t hs_set_profiling(hs_sim *sim, int32_t enabled);
 int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
 
+/* Developer-only: per-phase shader-clock sums of the physics kernel (all zero in release builds). */
+int32_t hs_debug_phase_cycles(hs_sim *sim, uint64_t out[16], int32_t reset);
+
 const char *hs_last_error(void);
 const char *hs_version(void);
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,7 @@ struct hs_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[3] = {0.f, 0.f, 0.f};
     bool initialised = false;
+    int group_lanes = 16;          // lanes per world in k_physics (4, 8 or 16); env HS_GROUP_LANES
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -65,11 +67,10 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
     const bool prof = s->profiling;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first) {
-        if (s->A <= 5) {
-            hipLaunchKernelGGL(hs::k_physics<16>, dim3((N + 3) / 4), dim3(64), 0, strm, S);
-        } else {
-            hipLaunchKernelGGL(hs::k_physics<32>, dim3((N + 1) / 2), dim3(64), 0, strm, S);
-        }
+        const int G = s->group_lanes;
+        if (G == 4) hipLaunchKernelGGL(hs::k_physics<4>, dim3((N + 15) / 16), dim3(64), 0, strm, S);
+        else if (G == 8) hipLaunchKernelGGL(hs::k_physics<8>, dim3((N + 7) / 8), dim3(64), 0, strm, S);
+        else hipLaunchKernelGGL(hs::k_physics<16>, dim3((N + 3) / 4), dim3(64), 0, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
@@ -108,6 +109,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     hs_sim *s = new hs_sim();
     s->cfg = *cfg;
     s->A = A;
+    if (const char *e = getenv("HS_GROUP_LANES")) { int g = atoi(e); if (g == 4 || g == 8 || g == 16) s->group_lanes = g; }
     hs::SimState &S = s->S;
     std::memset(&S, 0, sizeof(S));
     const size_t N = (size_t)cfg->num_worlds, R = N * (size_t)A;
@@ -132,6 +134,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xBoxObs, R * 9 * 17); HS_ALLOC(S.xRampObs, R * 2 * 14); HS_ALLOC(S.xVisAgents, R * 5);
     HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
+    HS_ALLOC(S.dbg, 16);
+    { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
 #undef HS_ALLOC
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
@@ -298,6 +302,14 @@ int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
         m[0] = nw[w]; m[1] = np[w]; m[2] = (c >> 12) & 15; m[3] = (c >> 16) & 15; m[4] = c & 15; m[5] = (c >> 4) & 15;
         m[6] = step[w]; m[7] = (c >> 20) & 1;
     }
+    return HS_OK;
+}
+
+// developer-only: per-phase shader-clock sums of k_physics (zeros unless built with -DHS_PHASE_TIMING)
+int32_t hs_debug_phase_cycles(hs_sim *s, uint64_t out[16], int32_t reset) {
+    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipMemcpy(out, s->S.dbg, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HS_HIP(hipMemset(s->S.dbg, 0, 16 * sizeof(uint64_t)));
     return HS_OK;
 }
 

@@ -21,19 +21,31 @@
 
 namespace hs {
 
-struct ManDD { int a, b, np; float muS, muD; float n[3]; float rA[4][3]; float rB[4][3]; float lam[4]; };
-struct ManS { int np; float muS, muD; float n[3]; float rA[4][3]; float offB[4]; float lam[4]; };
+// Developer-only phase timing (build with -DHS_PHASE_TIMING): per-phase shader-clock sums per wave.
+#ifdef HS_PHASE_TIMING
+#define HS_STAMP_INIT unsigned long long t_prev_ = clock64(); unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define HS_STAMP(i) { unsigned long long t_ = clock64(); acc_[i] += t_ - t_prev_; t_prev_ = t_; }
+#define HS_STAMP_FLUSH if (threadIdx.x == 0 && S.dbg) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&S.dbg[i_], acc_[i_]); }
+#else
+#define HS_STAMP_INIT
+#define HS_STAMP(i)
+#define HS_STAMP_FLUSH
+#endif
+
+// Contact manifolds live in an HBM workspace (L2-resident): written once by the lane that ran the
+// convex test, read by the lane that solves them.  16-byte multiples so they move as dwordx4.
+struct alignas(16) ManDD { int a, b, np; float muS, muD; float n[3]; float rA[4][3]; float rB[4][3]; float lam[4]; };
+struct alignas(16) ManS { int np; float muS, muD; float n[3]; float pad[2]; float rA[4][3]; float offB[4]; float lam[4]; };
+static_assert(sizeof(ManDD) == 144 && sizeof(ManS) == 112, "manifold layout");
 
 struct PhysWorld {
     WorldGeom g;
     float lin[kNumDSlots][3], ang[kNumDSlots][3];
     float ppos[kNumDSlots][3], prot[kNumDSlots][4];
     float lo[kNumDSlots][3], hi[kNumDSlots][3];
-    int cnt[32];
+    int cnt[kNumDSlots];          // per-slot candidate counts: body-body | body-static << 16
     int ndd, nsc;
     unsigned char ddA[kMaxDDCand], ddB[kMaxDDCand], scBody[kMaxSCand], scStatic[kMaxSCand];
-    ManDD dd[kMaxDDCand];
-    ManS sc[kMaxSCand];
     int grabOther[kMaxAgents];
     float grabData[kMaxAgents][8];
     float aforce[kMaxAgents][4];
@@ -271,9 +283,10 @@ HSD void action_system(PhysWorld &pw, int A_) {
 }
 
 template <int G>
-__global__ void __launch_bounds__(64) k_physics(SimState S) {
-    constexpr int W = 64 / G;
-    constexpr int SATL = 8;                 // lanes per group that run convex tests
+__global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
+    constexpr int W = 64 / G;                       // worlds per wave
+    constexpr int NB = (kNumDSlots + G - 1) / G;    // body slots owned by one lane: l, l+G, ...
+    constexpr int SATL = G >= 16 ? 4 : 2;           // lanes per group that run convex tests
     __shared__ PhysWorld sh[W];
     __shared__ ClipBuf clipbuf[W * SATL];
     const int lane = threadIdx.x;
@@ -282,11 +295,14 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
     const int N = S.N, A_ = S.A;
     const bool wok = w < N;
     PhysWorld &pw = sh[grp];
+    ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)(wok ? w : 0) * kMaxDDCand;
+    ManS *const wsSC = (ManS *)S.wsSC + (size_t)(wok ? w : 0) * kMaxSCand;
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     // developer-only timing ablations (results are wrong when set)
     const bool dbg_no_sat = S.flags & (1u << 24), dbg_no_dd = S.flags & (1u << 25), dbg_no_s = S.flags & (1u << 26);
     const bool dbg_no_cand = S.flags & (1u << 27);
 
+    HS_STAMP_INIT
     // ---------------- stage the world into LDS ----------------
     if (wok) {
         for (int s = l; s < kNumDSlots; s += G) {
@@ -325,50 +341,46 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
     }
     __syncthreads();
 
-    const int slot = l;                       // movable-body slot owned by this lane
-    const bool has_slot = wok && slot < kNumDSlots;
-    const int agent = slot - kAgentSlot0;     // agent interface index when >= 0
-    const bool is_agent_lane = has_slot && agent >= 0 && agent < A_;
-    bool acts = false;                        // agent takes part in movement/action this step
-    int32_t *act_row = nullptr;
-    if (is_agent_lane) {
-        const bool active = team_agent_active(pw.teams, agent) != 0;
-        const int type = team_agent_type(pw.teams, agent);
-        acts = active && !(type == AGENT_SEEKER && pw.step < kNumPrepSteps - 1);
-        act_row = S.xAction + (w * A_ + agent) * 5;
-    }
+    HS_STAMP(0)
     // ---------------- movementSystem / instantMovementSystem (sim.cpp:202-254) ----------------
-    if (acts) {
-        const int ax = act_row[0], ay = act_row[1], ar = act_row[2], ag = act_row[3], al = act_row[4];
-        float fx, fy, tz;
-        if (instant) { fx = 400.f * (float)(ax - 2); fy = 400.f * (float)(ay - 2); tz = 120.f * (float)(ar - 2); }
-        else { fx = 12.f * (float)(ax - 5); fy = 12.f * (float)(ay - 5); tz = 3.f * (float)(ar - 5); }
-        V3 f = qrot(geom_rot(pw.g, slot), {fx, fy, 0.f});
-        pw.aforce[agent][0] = f.x; pw.aforce[agent][1] = f.y; pw.aforce[agent][2] = f.z; pw.aforce[agent][3] = tz;
-        pw.actGL[agent] = (ag == 1 ? 1 : 0) | (al == 1 ? 2 : 0);
-        // "consume" the action (sim.cpp:365-369)
-        act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;
+    if (wok) {
+        for (int agent = l; agent < A_; agent += G) {
+            const bool active = team_agent_active(pw.teams, agent) != 0;
+            const int type = team_agent_type(pw.teams, agent);
+            if (!active || (type == AGENT_SEEKER && pw.step < kNumPrepSteps - 1)) continue;
+            int32_t *act_row = S.xAction + (w * A_ + agent) * 5;
+            const int ax = act_row[0], ay = act_row[1], ar = act_row[2], ag = act_row[3], al = act_row[4];
+            float fx, fy, tz;
+            if (instant) { fx = 400.f * (float)(ax - 2); fy = 400.f * (float)(ay - 2); tz = 120.f * (float)(ar - 2); }
+            else { fx = 12.f * (float)(ax - 5); fy = 12.f * (float)(ay - 5); tz = 3.f * (float)(ar - 5); }
+            V3 f = qrot(geom_rot(pw.g, kAgentSlot0 + agent), {fx, fy, 0.f});
+            pw.aforce[agent][0] = f.x; pw.aforce[agent][1] = f.y; pw.aforce[agent][2] = f.z; pw.aforce[agent][3] = tz;
+            pw.actGL[agent] = (ag == 1 ? 1 : 0) | (al == 1 ? 2 : 0);
+            // "consume" the action (sim.cpp:365-369)
+            act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;
+        }
     }
     __syncthreads();
     // ---------------- actionSystem (sim.cpp:270-370): rare, serial per world ----------------
     if (wok && l == 0) action_system(pw, A_);
     __syncthreads();
 
-    // per-lane constants of the owned body
-    V3 force = {0.f, 0.f, 0.f}; float torque_z = 0.f;
-    if (is_agent_lane) { force = ld3(pw.aforce[agent]); torque_z = pw.aforce[agent][3]; }
-
-    // ground-plane manifold of the owned body lives in registers
-    int g_np = 0; int g_vi[4] = {0, 0, 0, 0}; float g_off[4], g_lam[4]; V3 g_n = {0.f, 0.f, -1.f};
-    float g_muS = 0.f, g_muD = 0.f;
+    HS_STAMP(1)
+    // ground-plane manifolds of the owned bodies live in registers
+    int g_np[NB], g_vi[NB]; float g_off[NB][4], g_lam[NB][4];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) { g_np[jb] = 0; g_vi[jb] = 0; }
 
     for (int sub = 0; sub < 4; ++sub) {
-        const int meta = has_slot ? pw.g.meta[slot] : 0;
-        const int obj = meta_obj(meta);
-        const bool present = meta != 0;
-        const bool dynamic = present && meta_resp(meta) == RESP_DYNAMIC;
-        // ---------- P1: integrate, hull vertices, AABB ----------
-        if (has_slot) {
+        // ---------- P1: integrate, AABB ----------
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const int slot = l + jb * G;
+            if (!wok || slot >= kNumDSlots) continue;
+            const int meta = pw.g.meta[slot];
+            const int obj = meta_obj(meta);
+            const bool present = meta != 0;
+            const bool dynamic = present && meta_resp(meta) == RESP_DYNAMIC;
             V3 pos = ld3(pw.g.pos[slot]); Q rot = ld4(pw.g.rot[slot]);
             st3(pw.ppos[slot], pos); st4(pw.prot[slot], rot);
             if (dynamic) {
@@ -376,6 +388,8 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
                 V3 lin = ld3(pw.lin[slot]), ang = ld3(pw.ang[slot]);
                 const float invM = obj_inv_mass(obj);
                 const V3 invI = obj_inv_inertia(obj);
+                V3 force = {0.f, 0.f, 0.f}; float torque_z = 0.f;
+                if (slot >= kAgentSlot0) { force = ld3(pw.aforce[slot - kAgentSlot0]); torque_z = pw.aforce[slot - kAgentSlot0][3]; }
                 lin = lin + (force * invM + V3{0.f, 0.f, kGravityZ}) * h;
                 pos = pos + lin * h;
                 Q qi = qinv(rot);
@@ -395,71 +409,96 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
             }
         }
         __syncthreads();
-        // ---------- P2: candidate pairs, compacted in pair order ----------
-        unsigned dd_mask = 0; unsigned long long s_mask = 0ull; int s_planes = 0;
-        if (has_slot && present && !dbg_no_cand) {
-            const V3 lo = ld3(pw.lo[slot]), hi = ld3(pw.hi[slot]);
-            for (int j = slot + 1; j < kNumDSlots; ++j) {
-                const int mj = pw.g.meta[j];
-                if (mj == 0) continue;
-                if (!dynamic && meta_resp(mj) != RESP_DYNAMIC) continue;
-                const V3 lj = ld3(pw.lo[j]), hj = ld3(pw.hi[j]);
-                if (lo.x <= hj.x && lj.x <= hi.x && lo.y <= hj.y && lj.y <= hi.y && lo.z <= hj.z && lj.z <= hi.z)
-                    dd_mask |= 1u << j;
+        HS_STAMP(2)
+        // ---------- P2: candidate pairs, compacted in (slot, partner) order ----------
+        unsigned dd_mask[NB]; unsigned long long s_mask[NB]; int s_planes[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const int slot = l + jb * G;
+            dd_mask[jb] = 0; s_mask[jb] = 0ull; s_planes[jb] = 0;
+            if (!wok || slot >= kNumDSlots) continue;
+            const int meta = pw.g.meta[slot];
+            if (meta != 0 && !dbg_no_cand) {
+                const bool dynamic = meta_resp(meta) == RESP_DYNAMIC;
+                const V3 lo = ld3(pw.lo[slot]), hi = ld3(pw.hi[slot]);
+                for (int j = slot + 1; j < kNumDSlots; ++j) {
+                    const int mj = pw.g.meta[j];
+                    if (mj == 0) continue;
+                    if (!dynamic && meta_resp(mj) != RESP_DYNAMIC) continue;
+                    const V3 lj = ld3(pw.lo[j]), hj = ld3(pw.hi[j]);
+                    if (lo.x <= hj.x && lj.x <= hi.x && lo.y <= hj.y && lj.y <= hi.y && lo.z <= hj.z && lj.z <= hi.z)
+                        dd_mask[jb] |= 1u << j;
+                }
+                if (dynamic) {
+                    s_planes[jb] = pw.g.numPlanes > 1 ? pw.g.numPlanes - 1 : 0;
+                    const int nw = pw.g.numWalls;
+                    for (int k = 0; k < nw; ++k) {
+                        const float cx = pw.g.wall[k][0], cy = pw.g.wall[k][1], hx = pw.g.wall[k][2], hy = pw.g.wall[k][3];
+                        if (lo.x <= cx + hx && cx - hx <= hi.x && lo.y <= cy + hy && cy - hy <= hi.y && lo.z <= 2.5f && 0.f <= hi.z)
+                            s_mask[jb] |= 1ull << k;
+                    }
+                }
             }
-            if (dynamic) {
-                s_planes = pw.g.numPlanes > 1 ? pw.g.numPlanes - 1 : 0;
-                const int nw = pw.g.numWalls;
-                for (int k = 0; k < nw; ++k) {
-                    const float cx = pw.g.wall[k][0], cy = pw.g.wall[k][1], hx = pw.g.wall[k][2], hy = pw.g.wall[k][3];
-                    if (lo.x <= cx + hx && cx - hx <= hi.x && lo.y <= cy + hy && cy - hy <= hi.y && lo.z <= 2.5f && 0.f <= hi.z)
-                        s_mask |= 1ull << k;
+            pw.cnt[slot] = __popc(dd_mask[jb]) | ((s_planes[jb] + __popcll(s_mask[jb])) << 16);
+        }
+        __syncthreads();
+        if (wok) {
+            if (l == 0) {
+                int td = 0, ts = 0;
+                for (int k = 0; k < kNumDSlots; ++k) { const int c = pw.cnt[k]; td += c & 0xffff; ts += c >> 16; }
+                pw.ndd = td < kMaxDDCand ? td : kMaxDDCand; pw.nsc = ts < kMaxSCand ? ts : kMaxSCand;
+            }
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                const int slot = l + jb * G;
+                if (slot >= kNumDSlots) continue;
+                if (dd_mask[jb] == 0 && s_mask[jb] == 0ull && s_planes[jb] == 0) continue;
+                int off_dd = 0, off_sc = 0;
+                for (int k = 0; k < slot; ++k) { const int c = pw.cnt[k]; off_dd += c & 0xffff; off_sc += c >> 16; }
+                unsigned mm = dd_mask[jb];
+                while (mm) {
+                    const int j = __ffs(mm) - 1; mm &= mm - 1;
+                    if (off_dd < kMaxDDCand) { pw.ddA[off_dd] = (unsigned char)slot; pw.ddB[off_dd] = (unsigned char)j; }
+                    off_dd++;
+                }
+                for (int p = 1; p <= s_planes[jb]; ++p) {
+                    if (off_sc < kMaxSCand) { pw.scBody[off_sc] = (unsigned char)slot; pw.scStatic[off_sc] = (unsigned char)(kMaxWalls + p); }
+                    off_sc++;
+                }
+                unsigned long long sm = s_mask[jb];
+                while (sm) {
+                    const int k = __ffsll((long long)sm) - 1; sm &= sm - 1;
+                    if (off_sc < kMaxSCand) { pw.scBody[off_sc] = (unsigned char)slot; pw.scStatic[off_sc] = (unsigned char)k; }
+                    off_sc++;
                 }
             }
         }
-        const int my_dd = __popc(dd_mask), my_sc = s_planes + __popcll(s_mask);
-        if (wok) pw.cnt[l] = my_dd | (my_sc << 16);
         __syncthreads();
-        if (wok) {
-            int off_dd = 0, off_sc = 0, tot_dd = 0, tot_sc = 0;
-            for (int k = 0; k < G; ++k) {
-                const int c = pw.cnt[k];
-                if (k < l) { off_dd += c & 0xffff; off_sc += c >> 16; }
-                tot_dd += c & 0xffff; tot_sc += c >> 16;
-            }
-            if (l == 0) { pw.ndd = tot_dd < kMaxDDCand ? tot_dd : kMaxDDCand; pw.nsc = tot_sc < kMaxSCand ? tot_sc : kMaxSCand; }
-            unsigned mm = dd_mask;
-            while (mm) {
-                const int j = __ffs(mm) - 1; mm &= mm - 1;
-                if (off_dd < kMaxDDCand) { pw.ddA[off_dd] = (unsigned char)slot; pw.ddB[off_dd] = (unsigned char)j; }
-                off_dd++;
-            }
-            for (int p = 1; p <= s_planes; ++p) {
-                if (off_sc < kMaxSCand) { pw.scBody[off_sc] = (unsigned char)slot; pw.scStatic[off_sc] = (unsigned char)(kMaxWalls + p); }
-                off_sc++;
-            }
-            unsigned long long sm = s_mask;
-            while (sm) {
-                const int k = __ffsll((long long)sm) - 1; sm &= sm - 1;
-                if (off_sc < kMaxSCand) { pw.scBody[off_sc] = (unsigned char)slot; pw.scStatic[off_sc] = (unsigned char)k; }
-                off_sc++;
-            }
-        }
-        __syncthreads();
-        // ---------- P3: narrowphase, spread over the lanes of the group ----------
-        g_np = 0;
-        if (has_slot && dynamic && pw.g.numPlanes >= 1) {
+        HS_STAMP(3)
+        // ---------- P3: narrowphase ----------
+        // ground plane (plane 0): every movable body, result kept in the owner's registers
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const int slot = l + jb * G;
+            g_np[jb] = 0;
+            if (!wok || slot >= kNumDSlots || pw.g.numPlanes < 1) continue;
+            const int meta = pw.g.meta[slot];
+            if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) continue;
+            const int obj = meta_obj(meta);
             HullRef hb = hull_ref_body(obj, ld3(pw.g.pos[slot]), ld4(pw.g.rot[slot]));
             RawManifold raw;
-            const V3 pn = ld3(pw.g.plane[0]);
-            if (collide_hull_plane(hb, pn, pw.g.plane[0][3], raw)) {
-                g_np = raw.np; g_n = raw.n;
-                g_muS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
-                g_muD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+            if (collide_hull_plane(hb, ld3(pw.g.plane[0]), pw.g.plane[0][3], raw)) {
+                g_np[jb] = raw.np;
+                int vi = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { g_vi[j] = raw.vidx[j]; g_off[j] = dot(raw.pB[j], raw.n); g_lam[j] = 0.f; }
+                for (int j = 0; j < 4; ++j) {
+                    if (j < raw.np) { vi |= raw.vidx[j] << (3 * j); g_off[jb][j] = dot(raw.pB[j], raw.n); }
+                    g_lam[jb][j] = 0.f;
+                }
+                g_vi[jb] = vi;
             }
         }
+        HS_STAMP(4)
         if (wok && l < SATL) {
             // one work list: body-body pairs, then body-static pairs; both run the same convex test
             const int ndd = pw.ndd, ntot = pw.ndd + pw.nsc;
@@ -474,20 +513,22 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
                 const Q qa = ld4(pw.g.rot[a]);
                 const HullRef ha = hull_ref_body(oa, pa, qa);
                 RawManifold raw;
-                if (isdd) pw.dd[kk].np = 0; else pw.sc[kk].np = 0;
+                if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0;
                 if (dbg_no_sat) continue;
                 if (!isdd && bsel >= kMaxWalls) {
-                    ManS &m = pw.sc[kk];
                     const float *pl = pw.g.plane[bsel - kMaxWalls];
                     if (collide_hull_plane(ha, ld3(pl), pl[3], raw)) {
-                        m.np = raw.np; st3(m.n, raw.n);
+                        ManS m;
+                        m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
                         m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
                         m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (j < raw.np) {
-                            st3(m.rA[j], hull_local_vertex(oa, raw.vidx[j]));
-                            m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            const bool on = j < raw.np;
+                            st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
+                            m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                         }
+                        wsSC[kk] = m;
                     }
                     continue;
                 }
@@ -504,60 +545,85 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
                 const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
                 const Q qai = qinv(qa);
                 if (isdd) {
-                    ManDD &m = pw.dd[kk];
+                    ManDD m;
                     m.a = a; m.b = bsel; m.np = raw.np; m.muS = muS; m.muD = muD;
                     st3(m.n, raw.n);
                     const Q qbi = qinv(qb);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < raw.np) {
-                        st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
-                        st3(m.rB[j], qrot(qbi, raw.pB[j] - pb));
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = j < raw.np;
+                        st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                        st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
                         m.lam[j] = 0.f;
                     }
+                    wsDD[kk] = m;
                 } else {
-                    ManS &m = pw.sc[kk];
-                    m.np = raw.np; m.muS = muS; m.muD = muD;
+                    ManS m;
+                    m.np = raw.np; m.muS = muS; m.muD = muD; m.pad[0] = 0.f; m.pad[1] = 0.f;
                     st3(m.n, raw.n);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < raw.np) {
-                        st3(m.rA[j], qrot(qai, raw.pA[j] - pa));
-                        m.offB[j] = dot(raw.pB[j], raw.n); m.lam[j] = 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = j < raw.np;
+                        st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                        m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                     }
+                    wsSC[kk] = m;
                 }
             }
         }
         __syncthreads();
+        HS_STAMP(5)
         // ---------- P4: position solve ----------
         if (wok && l == 0 && !dbg_no_dd) {
             for (int a = 0; a < kMaxAgents; ++a)
                 if (team_agent_active(pw.teams, a)) solve_grab_joint(pw, a);
             const int ndd = pw.ndd;
             for (int k = 0; k < ndd; ++k) {
-                ManDD &m = pw.dd[k];
-                if (m.np <= 0) continue;
+                if (wsDD[k].np <= 0) continue;
+                ManDD m = wsDD[k];
                 BodyS Ab, Bb;
                 body_load(pw, m.a, Ab); body_load(pw, m.b, Bb);
                 const V3 n = ld3(m.n);
-                for (int j = 0; j < m.np; ++j)
-                    m.lam[j] += solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < m.np) m.lam[j] += solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
                 body_store_pose(pw, m.a, Ab); body_store_pose(pw, m.b, Bb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wsDD[k].lam[j] = m.lam[j];
             }
         }
         __syncthreads();
-        BodyS me; BodyS none;
-        if (has_slot && dynamic) {
+        HS_STAMP(6)
+        BodyS none;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const int slot = l + jb * G;
+            if (!wok || slot >= kNumDSlots) continue;
+            const int meta = pw.g.meta[slot];
+            if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) continue;
+            const int obj = meta_obj(meta);
+            BodyS me;
             body_load(pw, slot, me);
-            if (!dbg_no_s)
-            for (int j = 0; j < 4; ++j)
-                if (j < g_np) g_lam[j] += solve_point_position<false>(me, none, g_n, hull_local_vertex(obj, g_vi[j]), V3{0.f, 0.f, 0.f}, g_off[j], g_muS);
-            const int nsc = dbg_no_s ? 0 : pw.nsc;
-            for (int k = 0; k < nsc; ++k) {
-                if (pw.scBody[k] != slot) continue;
-                ManS &m = pw.sc[k];
-                if (m.np <= 0) continue;
-                const V3 n = ld3(m.n);
-                for (int j = 0; j < m.np; ++j)
-                    m.lam[j] += solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+            if (!dbg_no_s) {
+                const V3 gn = -ld3(pw.g.plane[0]);
+                const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < g_np[jb])
+                        g_lam[jb][j] += solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (g_vi[jb] >> (3 * j)) & 7),
+                                                                    V3{0.f, 0.f, 0.f}, g_off[jb][j], gmuS);
+                const int nsc = pw.nsc;
+                for (int k = 0; k < nsc; ++k) {
+                    if (pw.scBody[k] != slot) continue;
+                    if (wsSC[k].np <= 0) continue;
+                    ManS m = wsSC[k];
+                    const V3 n = ld3(m.n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < m.np) m.lam[j] += solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wsSC[k].lam[j] = m.lam[j];
+                }
             }
             // ---------- P5: derive velocities ----------
             const float h = kSubstepH;
@@ -568,59 +634,82 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
             body_store_pose(pw, slot, me); body_store_vel(pw, slot, me);
         }
         __syncthreads();
+        HS_STAMP(7)
         // ---------- P6: velocity solve ----------
         if (wok && l == 0 && !dbg_no_dd) {
             const int ndd = pw.ndd;
             for (int k = 0; k < ndd; ++k) {
-                const ManDD &m = pw.dd[k];
-                if (m.np <= 0) continue;
+                if (wsDD[k].np <= 0) continue;
+                const ManDD m = wsDD[k];
                 BodyS Ab, Bb;
                 body_load(pw, m.a, Ab); body_load(pw, m.b, Bb);
                 const V3 n = ld3(m.n);
-                for (int j = 0; j < m.np; ++j)
-                    solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
                 body_store_vel(pw, m.a, Ab); body_store_vel(pw, m.b, Bb);
             }
         }
         __syncthreads();
-        if (has_slot && dynamic && !dbg_no_s) {
+        HS_STAMP(8)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const int slot = l + jb * G;
+            if (!wok || slot >= kNumDSlots || dbg_no_s) continue;
+            const int meta = pw.g.meta[slot];
+            if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) continue;
+            const int obj = meta_obj(meta);
+            BodyS me;
             body_load(pw, slot, me);
+            const V3 gn = -ld3(pw.g.plane[0]);
+            const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < g_np) solve_point_velocity<false>(me, none, g_n, hull_local_vertex(obj, g_vi[j]), V3{0.f, 0.f, 0.f}, g_lam[j], g_muD);
+                if (j < g_np[jb])
+                    solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (g_vi[jb] >> (3 * j)) & 7), V3{0.f, 0.f, 0.f},
+                                                g_lam[jb][j], gmuD);
             const int nsc = pw.nsc;
             for (int k = 0; k < nsc; ++k) {
                 if (pw.scBody[k] != slot) continue;
-                const ManS &m = pw.sc[k];
-                if (m.np <= 0) continue;
+                if (wsSC[k].np <= 0) continue;
+                const ManS m = wsSC[k];
                 const V3 n = ld3(m.n);
-                for (int j = 0; j < m.np; ++j)
-                    solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
             }
             body_store_vel(pw, slot, me);
         }
         __syncthreads();
+        HS_STAMP(9)
     }
 
     // ---------------- agentZeroVelSystem (sim.cpp:258-268) ----------------
-    if (instant && has_slot && agent >= 0 && pw.g.meta[slot] != 0) {
-        pw.lin[slot][0] = 0.f; pw.lin[slot][1] = 0.f; pw.lin[slot][2] = fminf(pw.lin[slot][2], 0.f);
-        pw.ang[slot][0] = 0.f; pw.ang[slot][1] = 0.f; pw.ang[slot][2] = 0.f;
+    if (instant && wok) {
+        for (int agent = l; agent < kMaxAgents; agent += G) {
+            const int slot = kAgentSlot0 + agent;
+            if (pw.g.meta[slot] == 0) continue;
+            pw.lin[slot][0] = 0.f; pw.lin[slot][1] = 0.f; pw.lin[slot][2] = fminf(pw.lin[slot][2], 0.f);
+            pw.ang[slot][0] = 0.f; pw.ang[slot][1] = 0.f; pw.ang[slot][2] = 0.f;
+        }
     }
     __syncthreads();
 
-    // ---------------- rewardsVisSystem (sim.cpp:763-804): lanes = (seeker, hider) pairs ----------------
+    // ---------------- rewardsVisSystem (sim.cpp:763-804): work items = (seeker, hider) pairs ----------------
     bool seen = false;
-    if (wok && l < 9) {
-        const int si = l / 3, hi_ = l % 3;
-        if (si < cnt_seekers(pw.counts) && hi_ < cnt_hiders(pw.counts)) {
-            const int ss = kAgentSlot0 + team_seeker(pw.teams, si), hs_ = kAgentSlot0 + team_hider(pw.teams, hi_);
-            const V3 spos = geom_pos(pw.g, ss);
-            const V3 fwd = qrot(geom_rot(pw.g, ss), {0.f, 1.f, 0.f});
-            V3 to = geom_pos(pw.g, hs_) - spos;
-            float c = dot(normalize(to), fwd);
-            if (!(c < kCosFovHalf)) {
-                float t;
-                seen = trace_ray(pw.g, spos, to, 1.f, &t) == hs_;
+    if (wok) {
+        for (int it = l; it < 9; it += G) {
+            const int si = it / 3, hi_ = it % 3;
+            if (si < cnt_seekers(pw.counts) && hi_ < cnt_hiders(pw.counts)) {
+                const int ss = kAgentSlot0 + team_seeker(pw.teams, si), hs_ = kAgentSlot0 + team_hider(pw.teams, hi_);
+                const V3 spos = geom_pos(pw.g, ss);
+                const V3 fwd = qrot(geom_rot(pw.g, ss), {0.f, 1.f, 0.f});
+                V3 to = geom_pos(pw.g, hs_) - spos;
+                float c = dot(normalize(to), fwd);
+                if (!(c < kCosFovHalf)) {
+                    float t;
+                    if (trace_ray(pw.g, spos, to, 1.f, &t) == hs_) seen = true;
+                }
             }
         }
     }
@@ -628,18 +717,22 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
     __syncthreads();
 
     // ---------------- outputRewardsDonesSystem (sim.cpp:806-841) ----------------
-    if (is_agent_lane && team_agent_active(pw.teams, agent)) {
-        const int row = w * A_ + agent;
-        const int step = pw.step;
-        if (step == 0) S.xDone[row] = 0;
-        if (step < kNumPrepSteps - 1) {
-            S.xReward[row] = 0.f;
-        } else {
-            if (step == kEpisodeLen - 1) S.xDone[row] = 1;
-            float r = pw.hiderReward;
-            if (team_agent_type(pw.teams, agent) == AGENT_SEEKER) r *= -1.f;
-            if (fabsf(pw.g.pos[slot][0]) >= 18.f || fabsf(pw.g.pos[slot][1]) >= 18.f) r -= 10.f;
-            S.xReward[row] = r;
+    if (wok) {
+        for (int agent = l; agent < A_; agent += G) {
+            if (!team_agent_active(pw.teams, agent)) continue;
+            const int slot = kAgentSlot0 + agent;
+            const int row = w * A_ + agent;
+            const int step = pw.step;
+            if (step == 0) S.xDone[row] = 0;
+            if (step < kNumPrepSteps - 1) {
+                S.xReward[row] = 0.f;
+            } else {
+                if (step == kEpisodeLen - 1) S.xDone[row] = 1;
+                float r = pw.hiderReward;
+                if (team_agent_type(pw.teams, agent) == AGENT_SEEKER) r *= -1.f;
+                if (fabsf(pw.g.pos[slot][0]) >= 18.f || fabsf(pw.g.pos[slot][1]) >= 18.f) r -= 10.f;
+                S.xReward[row] = r;
+            }
         }
     }
     // ---------------- updateEpisodeResultsSystem (sim.cpp:843-893) ----------------
@@ -684,6 +777,8 @@ __global__ void __launch_bounds__(64) k_physics(SimState S) {
             for (int c = 0; c < 4; ++c) S.aforce[(c * kMaxAgents + i) * N + w] = pw.aforce[i][c];
         }
     }
+    HS_STAMP(10)
+    HS_STAMP_FLUSH
 }
 
 }  // namespace hs

@@ -60,21 +60,50 @@ HSD float ray_wedge_local(V3 o, V3 d) {
     return tn;
 }
 
+// Axis-aligned wall box with the per-ray reciprocal direction hoisted out of the wall loop (the same
+// quotients 1/d[k] the generic slab test computes, so results are bit-identical).
+HSD float ray_wall(V3 o, V3 d, V3 inv, V3 e) {
+    float tn = -3.0e38f, tf = 3.0e38f;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ee[3] = {e.x, e.y, e.z}, ii[3] = {inv.x, inv.y, inv.z};
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) miss = true; continue; }
+        float t0 = (-ee[k] - oo[k]) * ii[k], t1 = (ee[k] - oo[k]) * ii[k];
+        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+    }
+    if (miss || tn > tf || tn < 0.f) return -1.f;
+    return tn;
+}
+
+// Squared bounding-sphere radius of a movable hull about its origin, inflated by 2% so that the
+// conservative pre-test below can never reject a ray the exact test would accept.
+HSD float obj_bound_r2(int obj) {
+    return obj == OBJ_BOX ? 17.5625f * 1.02f : (obj == OBJ_RAMP ? 6.f * 1.02f : 3.f * 1.02f);
+}
+
 HSD int trace_ray(const WorldGeom &g, V3 o, V3 d, float tmax, float *t_out) {
     int hit = -1; float best = tmax;
+    const float dd2 = dot(d, d);
     for (int i = 0; i < kNumDSlots; ++i) {
         int m = g.meta[i];
         if (m == 0) continue;
         int obj = meta_obj(m);
+        // conservative cull: the ray misses the hull's bounding sphere, or the sphere lies behind the origin
+        const V3 mo = o - geom_pos(g, i);
+        const float b = dot(mo, d), cc = dot(mo, mo) - obj_bound_r2(obj);
+        if (cc > 0.f && (b > 0.f || b * b < dd2 * cc * 0.999f)) continue;
         Q qi = qinv(geom_rot(g, i));
-        V3 ol = qrot(qi, o - geom_pos(g, i)), dl = qrot(qi, d);
+        V3 ol = qrot(qi, mo), dl = qrot(qi, d);
         float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
         if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = i; }
     }
+    const V3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
     const int nw = g.numWalls;
     for (int k = 0; k < nw; ++k) {
         V3 ol = {o.x - g.wall[k][0], o.y - g.wall[k][1], o.z - 1.25f};
-        float t = ray_box_local(ol, d, {g.wall[k][2], g.wall[k][3], 1.25f});
+        float t = ray_wall(ol, d, inv, {g.wall[k][2], g.wall[k][3], 1.25f});
         if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + k; }
     }
     const int np = g.numPlanes;

@@ -49,6 +49,9 @@ struct SimState {
     int32_t *xReset, *xPrep, *xAction, *xSelfType, *xSeed, *xDone, *xPolicy;
     float *xSelfObs, *xSelfMask, *xAgentObs, *xBoxObs, *xRampObs, *xVisAgents, *xVisBoxes, *xVisRamps;
     float *xLidar, *xReward, *xGlobalPos, *xEpisodeResult;
+    // --- contact-manifold workspace (k_physics): [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
+    void *wsDD, *wsSC;
+    unsigned long long *dbg;   // [16] developer-only phase-cycle sums (HS_PHASE_TIMING builds)
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }

@@ -15,7 +15,7 @@ import os
 __all__ = ["HideAndSeekSimulator", "SimFlags", "madrona", "Tensor", "library_path"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhideseek.so")
+_LIB_PATH = os.environ.get("HS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libhideseek.so")
 
 
 def library_path():
