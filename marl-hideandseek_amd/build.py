@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libhideseek.so")
 
 # -ffp-contract=off / no fast-math: results are compared bit for bit with the CPU oracle.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-Wno-pass-failed", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-fast-math", "-Wno-unused-value"]
 
 

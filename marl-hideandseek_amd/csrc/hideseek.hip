@@ -39,7 +39,7 @@ struct hs_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[3] = {0.f, 0.f, 0.f};
     bool initialised = false;
-    int group_lanes = 16;          // lanes per world in k_physics (4, 8 or 16); env HS_GROUP_LANES
+    int block_threads = 128;       // k_physics workgroup size (128, 256, 512); env HS_BLOCK_THREADS
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -67,10 +67,10 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
     const bool prof = s->profiling;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first) {
-        const int G = s->group_lanes;
-        if (G == 4) hipLaunchKernelGGL(hs::k_physics<4>, dim3((N + 15) / 16), dim3(64), 0, strm, S);
-        else if (G == 8) hipLaunchKernelGGL(hs::k_physics<8>, dim3((N + 7) / 8), dim3(64), 0, strm, S);
-        else hipLaunchKernelGGL(hs::k_physics<16>, dim3((N + 3) / 4), dim3(64), 0, strm, S);
+        const int NT = s->block_threads;       // 16 lanes per world
+        if (s->A > 5) hipLaunchKernelGGL((hs::k_physics<128, 2>), dim3((N + 7) / 8), dim3(128), 0, strm, S);
+        else if (NT == 256) hipLaunchKernelGGL((hs::k_physics<256, 1>), dim3((N + 15) / 16), dim3(256), 0, strm, S);
+        else hipLaunchKernelGGL((hs::k_physics<128, 1>), dim3((N + 7) / 8), dim3(128), 0, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
@@ -109,7 +109,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     hs_sim *s = new hs_sim();
     s->cfg = *cfg;
     s->A = A;
-    if (const char *e = getenv("HS_GROUP_LANES")) { int g = atoi(e); if (g == 4 || g == 8 || g == 16) s->group_lanes = g; }
+    if (const char *e = getenv("HS_BLOCK_THREADS")) { int g = atoi(e); if (g == 128 || g == 256 || g == 512) s->block_threads = g; }
     hs::SimState &S = s->S;
     std::memset(&S, 0, sizeof(S));
     const size_t N = (size_t)cfg->num_worlds, R = N * (size_t)A;

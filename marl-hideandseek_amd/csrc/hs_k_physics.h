@@ -282,31 +282,41 @@ HSD void action_system(PhysWorld &pw, int A_) {
     }
 }
 
-template <int G>
-__global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
-    constexpr int W = 64 / G;                       // worlds per wave
-    constexpr int NB = (kNumDSlots + G - 1) / G;    // body slots owned by one lane: l, l+G, ...
-    constexpr int SATL = G >= 16 ? 4 : 2;           // lanes per group that run convex tests
-    __shared__ PhysWorld sh[W];
-    __shared__ ClipBuf clipbuf[W * SATL];
-    const int lane = threadIdx.x;
-    const int grp = lane / G, l = lane % G;
-    const int w = blockIdx.x * W + grp;
+// dynamic read / accumulate of a 4-entry register array without scratch
+HSD float sel4(const float (&a)[4], int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
+HSD void acc4(float (&a)[4], int j, float v) { a[0] += j == 0 ? v : 0.f; a[1] += j == 1 ? v : 0.f; a[2] += j == 2 ? v : 0.f; a[3] += j == 3 ? v : 0.f; }
+
+// Work-list entry helpers: (world-in-block << 8) | index
+HSD unsigned short item_pack(int world, int k) { return (unsigned short)((world << 8) | k); }
+
+template <int NT, int NB>   // NB = body slots per lane: 1 when agents <= 5 (slots 0..15), else 2
+__global__ void __launch_bounds__(NT, 2) k_physics(SimState S) {
+    constexpr int G = 16;                           // lanes per world
+    constexpr int WPB = NT / G;                     // worlds per workgroup
+    constexpr int PACK = 64;                        // sparse phases are packed into the first wave
+    __shared__ PhysWorld sh[WPB];
+    __shared__ ClipBuf clipbuf[PACK];
+    __shared__ unsigned short satItems[WPB * (kMaxDDCand + kMaxSCand)];
+    __shared__ unsigned short wallItems[WPB * kMaxSCand];
+    __shared__ unsigned char ddWorlds[WPB];
+    __shared__ int nSat, nWall, nDDW;
+    const int tid = threadIdx.x;
+    const int grp = tid / G, l = tid % G;
+    const int w = blockIdx.x * WPB + grp;
+    const int wbase = blockIdx.x * WPB;
     const int N = S.N, A_ = S.A;
     const bool wok = w < N;
     PhysWorld &pw = sh[grp];
-    ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)(wok ? w : 0) * kMaxDDCand;
-    ManS *const wsSC = (ManS *)S.wsSC + (size_t)(wok ? w : 0) * kMaxSCand;
+    ManDD *const wsDDb = (ManDD *)S.wsDD;
+    ManS *const wsSCb = (ManS *)S.wsSC;
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
-    // developer-only timing ablations (results are wrong when set)
-    const bool dbg_no_sat = S.flags & (1u << 24), dbg_no_dd = S.flags & (1u << 25), dbg_no_s = S.flags & (1u << 26);
-    const bool dbg_no_cand = S.flags & (1u << 27);
 
     HS_STAMP_INIT
     // ---------------- stage the world into LDS ----------------
     if (wok) {
         for (int s = l; s < kNumDSlots; s += G) {
             pw.g.meta[s] = S.bmeta[s * N + w];
+            pw.cnt[s] = 0;            // slots this block's lanes do not own (slot 16 when NB == 1) stay empty
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 pw.g.pos[s][c] = S.bpos[(c * kNumDSlots + s) * N + w];
@@ -337,7 +347,11 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
             pw.g.numWalls = nw; pw.g.numPlanes = npl;
             pw.counts = S.counts[w]; pw.teams = S.teams[w]; pw.step = S.curEpisodeStep[w];
             pw.hiderReward = S.hiderTeamReward[w];
+            pw.ndd = 0; pw.nsc = 0;
         }
+    } else if (l == 0) {
+        pw.g.numWalls = 0; pw.g.numPlanes = 0; pw.ndd = 0; pw.nsc = 0; pw.teams = 0; pw.counts = 0;
+        for (int s = 0; s < kNumDSlots; ++s) { pw.g.meta[s] = 0; pw.cnt[s] = 0; }
     }
     __syncthreads();
 
@@ -372,6 +386,7 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
     for (int jb = 0; jb < NB; ++jb) { g_np[jb] = 0; g_vi[jb] = 0; }
 
     for (int sub = 0; sub < 4; ++sub) {
+        if (tid == 0) { nSat = 0; nWall = 0; nDDW = 0; }
         // ---------- P1: integrate, AABB ----------
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
@@ -418,7 +433,7 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
             dd_mask[jb] = 0; s_mask[jb] = 0ull; s_planes[jb] = 0;
             if (!wok || slot >= kNumDSlots) continue;
             const int meta = pw.g.meta[slot];
-            if (meta != 0 && !dbg_no_cand) {
+            if (meta != 0) {
                 const bool dynamic = meta_resp(meta) == RESP_DYNAMIC;
                 const V3 lo = ld3(pw.lo[slot]), hi = ld3(pw.hi[slot]);
                 for (int j = slot + 1; j < kNumDSlots; ++j) {
@@ -444,9 +459,17 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
         __syncthreads();
         if (wok) {
             if (l == 0) {
-                int td = 0, ts = 0;
+                // totals of this world, and its entries in the block-wide sparse work lists
+                int td = 0, ts = 0; bool grab = false;
                 for (int k = 0; k < kNumDSlots; ++k) { const int c = pw.cnt[k]; td += c & 0xffff; ts += c >> 16; }
-                pw.ndd = td < kMaxDDCand ? td : kMaxDDCand; pw.nsc = ts < kMaxSCand ? ts : kMaxSCand;
+                const int ndd = td < kMaxDDCand ? td : kMaxDDCand, nsc = ts < kMaxSCand ? ts : kMaxSCand;
+                pw.ndd = ndd; pw.nsc = nsc;
+                for (int a = 0; a < kMaxAgents; ++a) grab |= pw.grabOther[a] >= 0;
+                if (ndd + nsc > 0) {
+                    const int base = atomicAdd(&nSat, ndd + nsc);
+                    for (int k = 0; k < ndd + nsc; ++k) satItems[base + k] = item_pack(grp, k);
+                }
+                if (ndd > 0 || grab) ddWorlds[atomicAdd(&nDDW, 1)] = (unsigned char)grp;
             }
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
@@ -455,6 +478,8 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
                 if (dd_mask[jb] == 0 && s_mask[jb] == 0ull && s_planes[jb] == 0) continue;
                 int off_dd = 0, off_sc = 0;
                 for (int k = 0; k < slot; ++k) { const int c = pw.cnt[k]; off_dd += c & 0xffff; off_sc += c >> 16; }
+                if ((s_mask[jb] != 0ull || s_planes[jb] != 0) && off_sc < kMaxSCand)
+                    wallItems[atomicAdd(&nWall, 1)] = item_pack(grp, slot);
                 unsigned mm = dd_mask[jb];
                 while (mm) {
                     const int j = __ffs(mm) - 1; mm &= mm - 1;
@@ -473,10 +498,8 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
                 }
             }
         }
-        __syncthreads();
         HS_STAMP(3)
-        // ---------- P3: narrowphase ----------
-        // ground plane (plane 0): every movable body, result kept in the owner's registers
+        // ---------- P3a: ground plane (plane 0) vs every owned body; result stays in registers ----------
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
             const int slot = l + jb * G;
@@ -498,25 +521,31 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
                 g_vi[jb] = vi;
             }
         }
+        __syncthreads();
         HS_STAMP(4)
-        if (wok && l < SATL) {
-            // one work list: body-body pairs, then body-static pairs; both run the same convex test
-            const int ndd = pw.ndd, ntot = pw.ndd + pw.nsc;
-            ClipBuf &cb = clipbuf[grp * SATL + l];
-            for (int k = l; k < ntot; k += SATL) {
+        // ---------- P3b: convex tests of the whole block, packed into the first wave ----------
+        if (tid < PACK) {
+            const int total = nSat;
+            ClipBuf &cb = clipbuf[tid];
+            for (int it = tid; it < total; it += PACK) {
+                const int item = satItems[it];
+                const int g2 = item >> 8, k = item & 0xff;
+                PhysWorld &q = sh[g2];
+                ManDD *const wsDD = wsDDb + (size_t)(wbase + g2) * kMaxDDCand;
+                ManS *const wsSC = wsSCb + (size_t)(wbase + g2) * kMaxSCand;
+                const int ndd = q.ndd;
                 const bool isdd = k < ndd;
                 const int kk = isdd ? k : k - ndd;
-                const int a = isdd ? pw.ddA[kk] : pw.scBody[kk];
-                const int bsel = isdd ? pw.ddB[kk] : pw.scStatic[kk];
-                const int oa = meta_obj(pw.g.meta[a]);
-                const V3 pa = ld3(pw.g.pos[a]);
-                const Q qa = ld4(pw.g.rot[a]);
+                const int a = isdd ? q.ddA[kk] : q.scBody[kk];
+                const int bsel = isdd ? q.ddB[kk] : q.scStatic[kk];
+                const int oa = meta_obj(q.g.meta[a]);
+                const V3 pa = ld3(q.g.pos[a]);
+                const Q qa = ld4(q.g.rot[a]);
                 const HullRef ha = hull_ref_body(oa, pa, qa);
                 RawManifold raw;
                 if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0;
-                if (dbg_no_sat) continue;
                 if (!isdd && bsel >= kMaxWalls) {
-                    const float *pl = pw.g.plane[bsel - kMaxWalls];
+                    const float *pl = q.g.plane[bsel - kMaxWalls];
                     if (collide_hull_plane(ha, ld3(pl), pl[3], raw)) {
                         ManS m;
                         m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
@@ -535,11 +564,11 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
                 int ob; V3 pb = {0.f, 0.f, 0.f}; Q qb = {1.f, 0.f, 0.f, 0.f};
                 HullRef hb;
                 if (isdd) {
-                    ob = meta_obj(pw.g.meta[bsel]); pb = ld3(pw.g.pos[bsel]); qb = ld4(pw.g.rot[bsel]);
+                    ob = meta_obj(q.g.meta[bsel]); pb = ld3(q.g.pos[bsel]); qb = ld4(q.g.rot[bsel]);
                     hb = hull_ref_body(ob, pb, qb);
                 } else {
                     ob = OBJ_WALL;
-                    hb = hull_ref_wall(pw.g.wall[bsel][0], pw.g.wall[bsel][1], pw.g.wall[bsel][2], pw.g.wall[bsel][3]);
+                    hb = hull_ref_wall(q.g.wall[bsel][0], q.g.wall[bsel][1], q.g.wall[bsel][2], q.g.wall[bsel][3]);
                 }
                 if (!collide_hulls(ha, hb, cb, raw)) continue;
                 const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
@@ -573,115 +602,163 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
         }
         __syncthreads();
         HS_STAMP(5)
-        // ---------- P4: position solve ----------
-        if (wok && l == 0 && !dbg_no_dd) {
-            for (int a = 0; a < kMaxAgents; ++a)
-                if (team_agent_active(pw.teams, a)) solve_grab_joint(pw, a);
-            const int ndd = pw.ndd;
-            for (int k = 0; k < ndd; ++k) {
-                if (wsDD[k].np <= 0) continue;
-                ManDD m = wsDD[k];
-                BodyS Ab, Bb;
-                body_load(pw, m.a, Ab); body_load(pw, m.b, Bb);
-                const V3 n = ld3(m.n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < m.np) m.lam[j] += solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
-                body_store_pose(pw, m.a, Ab); body_store_pose(pw, m.b, Bb);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wsDD[k].lam[j] = m.lam[j];
+        // ---------- P4a: joints + body-body manifolds, one lane per world that has any ----------
+        if (tid < PACK) {
+            const int total = nDDW;
+            for (int it = tid; it < total; it += PACK) {
+                const int g2 = ddWorlds[it];
+                PhysWorld &q = sh[g2];
+                ManDD *const wsDD = wsDDb + (size_t)(wbase + g2) * kMaxDDCand;
+                for (int a = 0; a < kMaxAgents; ++a)
+                    if (team_agent_active(q.teams, a)) solve_grab_joint(q, a);
+                const int ndd = q.ndd;
+                for (int k = 0; k < ndd; ++k) {
+                    if (wsDD[k].np <= 0) continue;
+                    ManDD &m = wsDD[k];
+                    const int ma = m.a, mb = m.b, mnp = m.np;
+                    const float muS = m.muS;
+                    BodyS Ab, Bb;
+                    body_load(q, ma, Ab); body_load(q, mb, Bb);
+                    const V3 n = ld3(m.n);
+#pragma unroll 1
+                    for (int j = 0; j < mnp; ++j)
+                        m.lam[j] += solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, muS);
+                    body_store_pose(q, ma, Ab); body_store_pose(q, mb, Bb);
+                }
             }
         }
         __syncthreads();
         HS_STAMP(6)
+        // ---------- P4b: ground manifold of every owned body ----------
         BodyS none;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const int slot = l + jb * G;
+            if (!wok || slot >= kNumDSlots || g_np[jb] == 0) continue;
+            const int obj = meta_obj(pw.g.meta[slot]);
+            BodyS me;
+            body_load(pw, slot, me);
+            const V3 gn = -ld3(pw.g.plane[0]);
+            const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+#pragma unroll 1
+            for (int j = 0; j < g_np[jb]; ++j)
+                acc4(g_lam[jb], j, solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (g_vi[jb] >> (3 * j)) & 7),
+                                                                V3{0.f, 0.f, 0.f}, sel4(g_off[jb], j), gmuS));
+            body_store_pose(pw, slot, me);
+        }
+        __syncthreads();
+        HS_STAMP(7)
+        // ---------- P4c: wall / extra-plane manifolds, one lane per body that has candidates ----------
+        if (tid < PACK) {
+            const int total = nWall;
+            for (int it = tid; it < total; it += PACK) {
+                const int item = wallItems[it];
+                const int g2 = item >> 8, slot = item & 0xff;
+                PhysWorld &q = sh[g2];
+                ManS *const wsSC = wsSCb + (size_t)(wbase + g2) * kMaxSCand;
+                BodyS me;
+                body_load(q, slot, me);
+                const int nsc = q.nsc;
+                for (int k = 0; k < nsc; ++k) {
+                    if (q.scBody[k] != slot) continue;
+                    if (wsSC[k].np <= 0) continue;
+                    ManS &m = wsSC[k];
+                    const int mnp = m.np; const float muS = m.muS;
+                    const V3 n = ld3(m.n);
+#pragma unroll 1
+                    for (int j = 0; j < mnp; ++j)
+                        m.lam[j] += solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], muS);
+                }
+                body_store_pose(q, slot, me);
+            }
+        }
+        __syncthreads();
+        HS_STAMP(8)
+        // ---------- P5: derive velocities ----------
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
             const int slot = l + jb * G;
             if (!wok || slot >= kNumDSlots) continue;
             const int meta = pw.g.meta[slot];
             if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) continue;
-            const int obj = meta_obj(meta);
-            BodyS me;
-            body_load(pw, slot, me);
-            if (!dbg_no_s) {
-                const V3 gn = -ld3(pw.g.plane[0]);
-                const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < g_np[jb])
-                        g_lam[jb][j] += solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (g_vi[jb] >> (3 * j)) & 7),
-                                                                    V3{0.f, 0.f, 0.f}, g_off[jb][j], gmuS);
-                const int nsc = pw.nsc;
-                for (int k = 0; k < nsc; ++k) {
-                    if (pw.scBody[k] != slot) continue;
-                    if (wsSC[k].np <= 0) continue;
-                    ManS m = wsSC[k];
+            const float h = kSubstepH;
+            const V3 pos = ld3(pw.g.pos[slot]), ppos = ld3(pw.ppos[slot]);
+            const Q rot = ld4(pw.g.rot[slot]), prot = ld4(pw.prot[slot]);
+            const V3 lin = (pos - ppos) * (1.f / h);
+            Q dq = qmul(rot, qinv(prot));
+            V3 wv = V3{dq.x, dq.y, dq.z} * (2.f / h);
+            st3(pw.lin[slot], lin); st3(pw.ang[slot], dq.w >= 0.f ? wv : -wv);
+        }
+        __syncthreads();
+        // ---------- P6a: body-body velocity pass ----------
+        if (tid < PACK) {
+            const int total = nDDW;
+            for (int it = tid; it < total; it += PACK) {
+                const int g2 = ddWorlds[it];
+                PhysWorld &q = sh[g2];
+                ManDD *const wsDD = wsDDb + (size_t)(wbase + g2) * kMaxDDCand;
+                const int ndd = q.ndd;
+                for (int k = 0; k < ndd; ++k) {
+                    if (wsDD[k].np <= 0) continue;
+                    const ManDD &m = wsDD[k];
+                    const int ma = m.a, mb = m.b, mnp = m.np;
+                    const float muD = m.muD;
+                    BodyS Ab, Bb;
+                    body_load(q, ma, Ab); body_load(q, mb, Bb);
                     const V3 n = ld3(m.n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < m.np) m.lam[j] += solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wsSC[k].lam[j] = m.lam[j];
+#pragma unroll 1
+                    for (int j = 0; j < mnp; ++j)
+                        solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], muD);
+                    body_store_vel(q, ma, Ab); body_store_vel(q, mb, Bb);
                 }
             }
-            // ---------- P5: derive velocities ----------
-            const float h = kSubstepH;
-            me.lin = (me.pos - me.ppos) * (1.f / h);
-            Q dq = qmul(me.rot, qinv(me.prot));
-            V3 wv = V3{dq.x, dq.y, dq.z} * (2.f / h);
-            me.ang = dq.w >= 0.f ? wv : -wv;
-            body_store_pose(pw, slot, me); body_store_vel(pw, slot, me);
         }
         __syncthreads();
-        HS_STAMP(7)
-        // ---------- P6: velocity solve ----------
-        if (wok && l == 0 && !dbg_no_dd) {
-            const int ndd = pw.ndd;
-            for (int k = 0; k < ndd; ++k) {
-                if (wsDD[k].np <= 0) continue;
-                const ManDD m = wsDD[k];
-                BodyS Ab, Bb;
-                body_load(pw, m.a, Ab); body_load(pw, m.b, Bb);
-                const V3 n = ld3(m.n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
-                body_store_vel(pw, m.a, Ab); body_store_vel(pw, m.b, Bb);
-            }
-        }
-        __syncthreads();
-        HS_STAMP(8)
+        HS_STAMP(9)
+        // ---------- P6b: ground velocity pass ----------
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
             const int slot = l + jb * G;
-            if (!wok || slot >= kNumDSlots || dbg_no_s) continue;
-            const int meta = pw.g.meta[slot];
-            if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) continue;
-            const int obj = meta_obj(meta);
+            if (!wok || slot >= kNumDSlots || g_np[jb] == 0) continue;
+            const int obj = meta_obj(pw.g.meta[slot]);
             BodyS me;
             body_load(pw, slot, me);
             const V3 gn = -ld3(pw.g.plane[0]);
             const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < g_np[jb])
-                    solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (g_vi[jb] >> (3 * j)) & 7), V3{0.f, 0.f, 0.f},
-                                                g_lam[jb][j], gmuD);
-            const int nsc = pw.nsc;
-            for (int k = 0; k < nsc; ++k) {
-                if (pw.scBody[k] != slot) continue;
-                if (wsSC[k].np <= 0) continue;
-                const ManS m = wsSC[k];
-                const V3 n = ld3(m.n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
-            }
+#pragma unroll 1
+            for (int j = 0; j < g_np[jb]; ++j)
+                solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (g_vi[jb] >> (3 * j)) & 7), V3{0.f, 0.f, 0.f},
+                                            sel4(g_lam[jb], j), gmuD);
             body_store_vel(pw, slot, me);
         }
         __syncthreads();
-        HS_STAMP(9)
+        HS_STAMP(10)
+        // ---------- P6c: wall / extra-plane velocity pass ----------
+        if (tid < PACK) {
+            const int total = nWall;
+            for (int it = tid; it < total; it += PACK) {
+                const int item = wallItems[it];
+                const int g2 = item >> 8, slot = item & 0xff;
+                PhysWorld &q = sh[g2];
+                ManS *const wsSC = wsSCb + (size_t)(wbase + g2) * kMaxSCand;
+                BodyS me;
+                body_load(q, slot, me);
+                const int nsc = q.nsc;
+                for (int k = 0; k < nsc; ++k) {
+                    if (q.scBody[k] != slot) continue;
+                    if (wsSC[k].np <= 0) continue;
+                    const ManS &m = wsSC[k];
+                    const int mnp = m.np; const float muD = m.muD;
+                    const V3 n = ld3(m.n);
+#pragma unroll 1
+                    for (int j = 0; j < mnp; ++j)
+                        solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], muD);
+                }
+                body_store_vel(q, slot, me);
+            }
+        }
+        __syncthreads();
+        HS_STAMP(11)
     }
 
     // ---------------- agentZeroVelSystem (sim.cpp:258-268) ----------------
@@ -777,7 +854,6 @@ __global__ void __launch_bounds__(64, 2) k_physics(SimState S) {
             for (int c = 0; c < 4; ++c) S.aforce[(c * kMaxAgents + i) * N + w] = pw.aforce[i][c];
         }
     }
-    HS_STAMP(10)
     HS_STAMP_FLUSH
 }
 
