@@ -1,23 +1,37 @@
 // Observation kernel: collectObservationsSystem (src/sim.cpp:448-565), computeVisibilitySystem CPU
 // branch (:567-605,663-708), lidarSystem (:712-759), globalPositionsDebugSystem (:895-941).
 //
-// One 256-thread workgroup per world.  The world's poses, velocities and static geometry are
-// staged once into LDS (coalesced dword loads from the world-fastest SoA columns); work items are
-// then spread over the threads as [A*30 lidar rays][A*16 visibility rays][A*17 relative-obs
-// entities][1 debug-positions item], which keeps each 64-lane wave on one kind of item.  The
-// reference's GPU branch uses a 32-lane warp per agent with 17/30 lanes busy; here a
-// wave64 is filled with rays of several agents of the same world instead.
+// One 256-thread workgroup per world; the world's poses, velocities and static geometry are
+// staged once into LDS (coalesced dword loads from the world-fastest SoA columns).
+//
+// Rays (A*30 lidar + A*16 visibility) are cast in two passes so that the expensive, divergent part
+// runs on full waves:
+//   1. one thread per ray: set the ray up, test it against the axis-aligned walls and the planes
+//      (uniform loops), and run a conservative bounding-sphere cull against the <= 17 movable hulls;
+//      every surviving (ray, hull) pair is appended to a pair list in LDS;
+//   2. one thread per PAIR: exact ray-vs-hull test, result merged into the ray's
+//      (t, body id) key with a 64-bit LDS atomic min — lexicographic (t, id) order is exactly the
+//      "closest hit, ties keep the lower id" rule of the sequential trace_ray.
+// The reference's GPU branch uses a 32-lane warp per agent with 17/30 lanes busy.
 #pragma once
 #include "hs_state.h"
 #include "hs_rays.h"
 
 namespace hs {
 
+constexpr int kRaysPerAgent = 46;                          // 30 lidar + 16 visibility targets
+constexpr int kMaxRays = kMaxAgents * kRaysPerAgent;       // 276
+constexpr int kMaxPairs = 1536;
+
 struct ObsShared {
     WorldGeom g;
     float lin[kNumDSlots][3];
     float ang[kNumDSlots][3];
     int grab[kMaxAgents];
+    float rayO[kMaxRays][3], rayD[kMaxRays][3];
+    unsigned long long rayKey[kMaxRays];
+    unsigned short pairs[kMaxPairs];                       // ray << 5 | body slot
+    int nPairs;
 };
 
 HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
@@ -41,7 +55,7 @@ HSD void stage_world(const SimState &S, int w, ObsShared &sh, int tid) {
         sh.g.rot[s][c] = S.brot[(c * kNumDSlots + s) * N + w];
     }
     const int nw = S.numWalls[w], np = S.numPlanes[w];
-    if (tid == 0) { sh.g.numWalls = nw; sh.g.numPlanes = np; }
+    if (tid == 0) { sh.g.numWalls = nw; sh.g.numPlanes = np; sh.nPairs = 0; }
     for (int i = tid; i < nw * 4; i += NT) {
         int c = i / nw, k = i % nw;
         sh.g.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
@@ -53,14 +67,8 @@ HSD void stage_world(const SimState &S, int w, ObsShared &sh, int tid) {
     for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther[i * N + w];
 }
 
-// checkVisibility lambda (sim.cpp:586-605)
-HSD float check_visibility(const WorldGeom &g, V3 me_pos, V3 fwd, int slot) {
-    V3 to = geom_pos(g, slot) - me_pos;
-    float c = dot(normalize(to), fwd);
-    if (c < kCosFovHalf) return 0.f;
-    float t;
-    return trace_ray(g, me_pos, to, 1.f, &t) == slot ? 1.f : 0.f;
-}
+HSD unsigned long long ray_key(float t, int id) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id; }
+constexpr unsigned kKeyMiss = 0xffffffffu;
 
 __global__ void __launch_bounds__(256) k_observe(SimState S) {
     __shared__ ObsShared sh;
@@ -74,54 +82,132 @@ __global__ void __launch_bounds__(256) k_observe(SimState S) {
     __syncthreads();
     const WorldGeom &g = sh.g;
     const int nAgents = cnt_agents(counts), nBoxes = cnt_boxes(counts), nRamps = cnt_ramps(counts);
-    const int nLidar = A * 30, nVis = A * 16, nObs = A * 17;
-    const int total = nLidar + nVis + nObs + 1;
-    for (int item = tid; item < total; item += 256) {
-        if (item < nLidar) {
-            // ---- lidarSystem: 30 rays in the agent's horizontal plane, t_max 200
-            const int i = item / 30, k = item % 30;
-            if (i >= nAgents) continue;
-            const int slot = kAgentSlot0 + i;
-            const Q rot = geom_rot(g, slot);
-            const V3 pos = geom_pos(g, slot);
-            V3 fwd = qrot(rot, {0.f, 1.f, 0.f}), right = qrot(rot, {1.f, 0.f, 0.f});
+    const int nRays = A * kRaysPerAgent;
+
+    // ---------------- pass 1: ray setup, walls + planes, cull against the movable hulls ----------------
+    for (int r = tid; r < nRays; r += 256) {
+        const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
+        sh.rayKey[r] = ray_key(-1.f, kKeyMiss);               // "no ray" (visibility ray not cast)
+        if (i >= nAgents) continue;
+        const int slot = kAgentSlot0 + i;
+        const Q rot = geom_rot(g, slot);
+        const V3 o = geom_pos(g, slot);
+        const V3 fwd = qrot(rot, {0.f, 1.f, 0.f});
+        V3 d; float tmax;
+        if (k < 30) {
+            // lidarSystem: 30 rays in the agent's horizontal plane, t_max 200 (sim.cpp:727-738)
+            const V3 right = qrot(rot, {1.f, 0.f, 0.f});
             float theta = 2.f * kPi * ((float)k / 30.f) + kPi / 2.f;
             float s, c; hs_sincosf(theta, &s, &c);
-            V3 dir = normalize(right * c + fwd * s);
-            float t;
-            int hit = trace_ray(g, pos, dir, 200.f, &t);
-            S.xLidar[(w * A + i) * 30 + k] = hit < 0 ? 0.f : t;
-        } else if (item < nLidar + nVis) {
-            // ---- computeVisibilitySystem: FOV cone + segment ray to each box / ramp / other agent
-            const int v = item - nLidar;
-            const int i = v / 16, e = v % 16;
-            if (i >= nAgents) continue;
-            const int row = w * A + i;
-            const int slot = kAgentSlot0 + i;
-            const V3 pos = geom_pos(g, slot);
-            const V3 fwd = qrot(geom_rot(g, slot), {0.f, 1.f, 0.f});
+            d = normalize(right * c + fwd * s);
+            tmax = 200.f;
+        } else {
+            // checkVisibility (sim.cpp:586-605): FOV cone, then a segment ray to the target's origin
+            const int e = k - 30;
+            int tslot; bool present;
+            if (e < kMaxBoxes) { tslot = kBoxSlot0 + e; present = e < nBoxes; }
+            else if (e < kMaxBoxes + kMaxRamps) { tslot = kRampSlot0 + (e - kMaxBoxes); present = (e - kMaxBoxes) < nRamps; }
+            else { const int jj = e - kMaxBoxes - kMaxRamps; const int j = jj < i ? jj : jj + 1; tslot = kAgentSlot0 + j; present = j < nAgents; }
+            if (!present) continue;
+            d = geom_pos(g, tslot) - o;
+            if (dot(normalize(d), fwd) < kCosFovHalf) continue;
+            tmax = 1.f;
+        }
+        sh.rayO[r][0] = o.x; sh.rayO[r][1] = o.y; sh.rayO[r][2] = o.z;
+        sh.rayD[r][0] = d.x; sh.rayD[r][1] = d.y; sh.rayD[r][2] = d.z;
+        // static geometry: same order and arithmetic as trace_ray
+        int hit = -1; float best = tmax;
+        const V3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
+        const int nw = g.numWalls;
+        for (int q = 0; q < nw; ++q) {
+            V3 ol = {o.x - g.wall[q][0], o.y - g.wall[q][1], o.z - 1.25f};
+            float t = ray_wall(ol, d, inv, {g.wall[q][2], g.wall[q][3], 1.25f});
+            if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + q; }
+        }
+        const int np = g.numPlanes;
+        for (int p = 0; p < np; ++p) {
+            V3 n = {g.plane[p][0], g.plane[p][1], g.plane[p][2]};
+            float dn = dot(n, d);
+            if (!(dn < 0.f)) continue;
+            float dist = dot(n, o) - g.plane[p][3];
+            if (dist < 0.f) continue;
+            float t = -dist / dn;
+            if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitPlaneBase + p; }
+        }
+        unsigned long long key = hit < 0 ? ray_key(tmax, kKeyMiss) : ray_key(best, hit);
+        // movable hulls: conservative cull here, exact test in pass 2
+        const float dd2 = dot(d, d);
+        for (int b = 0; b < kNumDSlots; ++b) {
+            const int m = g.meta[b];
+            if (m == 0) continue;
+            const int obj = meta_obj(m);
+            const V3 mo = o - geom_pos(g, b);
+            const float bb = dot(mo, d), cc = dot(mo, mo) - obj_bound_r2(obj);
+            if (cc > 0.f && (bb > 0.f || bb * bb < dd2 * cc * 0.999f)) continue;
+            const int slotp = atomicAdd(&sh.nPairs, 1);
+            if (slotp < kMaxPairs) {
+                sh.pairs[slotp] = (unsigned short)((r << 5) | b);
+            } else {
+                // pair list full: test in place
+                Q qi = qinv(geom_rot(g, b));
+                V3 ol = qrot(qi, mo), dl = qrot(qi, d);
+                float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
+                if (t >= 0.f && t <= tmax) { unsigned long long kk = ray_key(t, b); key = kk < key ? kk : key; }
+            }
+        }
+        sh.rayKey[r] = key;
+    }
+    __syncthreads();
+    // ---------------- pass 2: exact ray-vs-hull tests, one thread per surviving pair ----------------
+    {
+        const int np2 = sh.nPairs < kMaxPairs ? sh.nPairs : kMaxPairs;
+        for (int p = tid; p < np2; p += 256) {
+            const int pr = sh.pairs[p];
+            const int r = pr >> 5, b = pr & 31;
+            const int obj = meta_obj(g.meta[b]);
+            const V3 o = {sh.rayO[r][0], sh.rayO[r][1], sh.rayO[r][2]};
+            const V3 d = {sh.rayD[r][0], sh.rayD[r][1], sh.rayD[r][2]};
+            const float tmax = (r % kRaysPerAgent) < 30 ? 200.f : 1.f;
+            Q qi = qinv(geom_rot(g, b));
+            V3 ol = qrot(qi, o - geom_pos(g, b)), dl = qrot(qi, d);
+            float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
+            if (t >= 0.f && t <= tmax) atomicMin(&sh.rayKey[r], ray_key(t, b));
+        }
+    }
+    __syncthreads();
+    // ---------------- pass 3: ray results -> exported columns ----------------
+    for (int r = tid; r < nRays; r += 256) {
+        const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
+        if (i >= nAgents) continue;
+        const int row = w * A + i;
+        const unsigned long long key = sh.rayKey[r];
+        const unsigned id = (unsigned)(key & 0xffffffffull);
+        const float t = __uint_as_float((unsigned)(key >> 32));
+        if (k < 30) {
+            S.xLidar[row * 30 + k] = id == kKeyMiss ? 0.f : t;
+        } else {
+            const int e = k - 30;
             if (e < kMaxBoxes) {
-                S.xVisBoxes[row * kMaxBoxes + e] = e < nBoxes ? check_visibility(g, pos, fwd, kBoxSlot0 + e) : 0.f;
+                S.xVisBoxes[row * kMaxBoxes + e] = (id == (unsigned)(kBoxSlot0 + e)) ? 1.f : 0.f;
             } else if (e < kMaxBoxes + kMaxRamps) {
-                const int r = e - kMaxBoxes;
-                S.xVisRamps[row * kMaxRamps + r] = r < nRamps ? check_visibility(g, pos, fwd, kRampSlot0 + r) : 0.f;
+                const int rr = e - kMaxBoxes;
+                S.xVisRamps[row * kMaxRamps + rr] = (id == (unsigned)(kRampSlot0 + rr)) ? 1.f : 0.f;
             } else {
                 const int jj = e - kMaxBoxes - kMaxRamps;
                 const int j = jj < i ? jj : jj + 1;
-                float vis = 0.f;
-                if (j < nAgents) {
-                    vis = check_visibility(g, pos, fwd, kAgentSlot0 + j);
-                    // CPU-branch side effect (sim.cpp:700-705): all writers store the same value
-                    if (team_agent_type(teams, i) == AGENT_SEEKER && vis != 0.f &&
-                        team_agent_type(teams, j) == AGENT_HIDER)
-                        S.hiderTeamReward[w] = -1.f;
-                }
+                const float vis = (id == (unsigned)(kAgentSlot0 + j)) ? 1.f : 0.f;
+                // CPU-branch side effect (sim.cpp:700-705): all writers store the same value
+                if (vis != 0.f && team_agent_type(teams, i) == AGENT_SEEKER && team_agent_type(teams, j) == AGENT_HIDER)
+                    S.hiderTeamReward[w] = -1.f;
                 S.xVisAgents[row * (kMaxAgents - 1) + jj] = vis;
             }
-        } else if (item < nLidar + nVis + nObs) {
-            // ---- collectObservationsSystem: self / box / ramp / other-agent rows
-            const int v = item - nLidar - nVis;
-            const int i = v / 17, e = v % 17;
+        }
+    }
+    // ---------------- collectObservationsSystem rows + globalPositionsDebugSystem ----------------
+    const int nObs = A * 17;
+    for (int item = tid; item < nObs + 1; item += 256) {
+        if (item < nObs) {
+            const int i = item / 17, e = item % 17;
             if (i >= nAgents) continue;
             const int row = w * A + i;
             const int slot = kAgentSlot0 + i;
