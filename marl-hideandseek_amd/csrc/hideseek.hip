@@ -12,7 +12,8 @@
 #include "hs_state.h"
 #include "hs_k_reset.h"
 #include "hs_k_observe.h"
-#include "hs_k_physics.h"
+#include "hs_k_pipeline.h"
+#include "hs_solver.h"
 
 namespace {
 
@@ -39,7 +40,6 @@ struct hs_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[3] = {0.f, 0.f, 0.f};
     bool initialised = false;
-    int block_threads = 128;       // k_physics workgroup size (128, 256, 512); env HS_BLOCK_THREADS
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -67,10 +67,24 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
     const bool prof = s->profiling;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first) {
-        const int NT = s->block_threads;       // 16 lanes per world
-        if (s->A > 5) hipLaunchKernelGGL((hs::k_physics<128, 2>), dim3((N + 7) / 8), dim3(128), 0, strm, S);
-        else if (NT == 256) hipLaunchKernelGGL((hs::k_physics<256, 1>), dim3((N + 15) / 16), dim3(256), 0, strm, S);
-        else hipLaunchKernelGGL((hs::k_physics<128, 1>), dim3((N + 7) / 8), dim3(128), 0, strm, S);
+        // movement + actionSystem, 4 XPBD substeps (9 kernels each), rewards / dones / episode results
+        const int NS = hs::kAgentSlot0 + s->A;                 // body slots in use
+        const dim3 gridBody((NS * N + 255) / 256), gridWorld((N + 15) / 16);
+        const int sparse = N / 64 < 64 ? 64 : (N / 64 > 2048 ? 2048 : N / 64);   // grid-stride grids of the packed kernels
+        hipLaunchKernelGGL(hs::k_pre, gridWorld, dim3(256), 0, strm, S);
+        for (int sub = 0; sub < 4; ++sub) {
+            const int par = sub & 1;
+            hipLaunchKernelGGL(hs::k_integrate, gridBody, dim3(256), 0, strm, S, NS, par);
+            hipLaunchKernelGGL(hs::k_detect, dim3((N + 63) / 64), dim3(1024), 0, strm, S, NS, par);
+            hipLaunchKernelGGL(hs::k_sat, dim3(sparse * 2), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_dd_pos, dim3(sparse), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_ground_pos, gridBody, dim3(256), 0, strm, S, NS);
+            hipLaunchKernelGGL(hs::k_walls_pos, dim3(sparse), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_dd_vel, dim3(sparse), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_ground_vel, gridBody, dim3(256), 0, strm, S, NS);
+            hipLaunchKernelGGL(hs::k_walls_vel, dim3(sparse), dim3(64), 0, strm, S, par);
+        }
+        hipLaunchKernelGGL(hs::k_post, gridWorld, dim3(256), 0, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
@@ -109,7 +123,6 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     hs_sim *s = new hs_sim();
     s->cfg = *cfg;
     s->A = A;
-    if (const char *e = getenv("HS_BLOCK_THREADS")) { int g = atoi(e); if (g == 128 || g == 256 || g == 512) s->block_threads = g; }
     hs::SimState &S = s->S;
     std::memset(&S, 0, sizeof(S));
     const size_t N = (size_t)cfg->num_worlds, R = N * (size_t)A;
@@ -136,6 +149,12 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
     HS_ALLOC(S.dbg, 16);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
+    HS_ALLOC(S.bppos, 3 * D * N); HS_ALLOC(S.bprot, 4 * D * N); HS_ALLOC(S.blo, 3 * D * N); HS_ALLOC(S.bhi, 3 * D * N);
+    HS_ALLOC(S.gman, D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
+    HS_ALLOC(S.ndd, N); HS_ALLOC(S.nsc, N); HS_ALLOC(S.ddPair, hs::kMaxDDCand * N); HS_ALLOC(S.scPair, hs::kMaxSCand * N);
+    HS_ALLOC(S.wflags, N);
+    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.ddwList, 2 * N);
+    HS_ALLOC(S.counters, 8);
 #undef HS_ALLOC
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {

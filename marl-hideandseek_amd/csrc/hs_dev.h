@@ -29,8 +29,8 @@ constexpr int kEpisodeLen = 240;
 constexpr float kSubstepH = (1.f / 30.f) / 4.f;
 constexpr float kGravityZ = -9.8f;
 constexpr float kMaxDepenVel = 3.f;
-constexpr int kMaxDDCand = 8;
-constexpr int kMaxSCand = 12;
+constexpr int kMaxDDCand = 16;
+constexpr int kMaxSCand = 24;
 constexpr float kCosFovHalf = 0.382683426f;
 constexpr float kPi = 3.14159265358979323846f;
 

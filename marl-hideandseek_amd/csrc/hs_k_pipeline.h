@@ -1,0 +1,762 @@
+// Physics substep pipeline: PhysicsSystem::setupPhysicsStepTasks (src/sim.cpp:1162-1163; engine
+// source absent — DESIGN.md "Engine decisions") as a sequence of small kernels over the SoA columns.
+//
+// Per-body work runs with SLOT-MAJOR lanes: thread t -> slot = t / N, world = t % N, so the 64
+// lanes of a wave hold the same body slot of 64 consecutive worlds: every state access is a
+// coalesced dword load/store of a world-fastest column, lanes share the hull type, and all lanes
+// have work (ground contacts exist for every body).  The sparse work — convex tests of candidate
+// pairs, body-body manifolds, wall manifolds — is compacted into GLOBAL work lists with a
+// wavefront ballot + prefix (one atomic per wave) and then processed one lane per item, so those
+// kernels also run on full waves instead of a few lanes per world.
+//
+// Substep s:
+//   k_integrate      slot-major   integrate, previous pose, AABB; per-world candidate counters = 0
+//   k_detect         slot-major   all-pairs AABB candidates -> per-world lists + global lists;
+//                                 ground-plane manifold of every body
+//   k_sat            per pair     exact convex test -> manifold workspace
+//   k_dd_pos         per world*   joints, then body-body manifolds in (i<j) order   (*worlds that have any)
+//   k_ground_pos     slot-major   ground manifold; velocity derivation for bodies without wall candidates
+//   k_walls_pos      per body*    wall / extra-plane manifolds in static order; velocity derivation
+//   k_dd_vel         per world*   body-body velocity pass
+//   k_ground_vel     slot-major   ground velocity pass
+//   k_walls_vel      per body*    wall velocity pass
+// The Gauss-Seidel order and every rounding are the oracle's (joints, body-body in pair order,
+// then per body: ground, walls by static id); candidate lists are unordered and sorted on use.
+#pragma once
+#include "hs_state.h"
+#include "hs_rays.h"
+#include "hs_collide.h"
+#include "hs_solver.h"
+
+namespace hs {
+
+// ---- SoA accessors ----
+HSD int bidx(const SimState &S, int c, int slot, int w) { return (c * kNumDSlots + slot) * S.N + w; }
+HSD V3 gld3(const float *col, const SimState &S, int slot, int w) {
+    return {col[bidx(S, 0, slot, w)], col[bidx(S, 1, slot, w)], col[bidx(S, 2, slot, w)]};
+}
+HSD Q gld4(const float *col, const SimState &S, int slot, int w) {
+    return {col[bidx(S, 0, slot, w)], col[bidx(S, 1, slot, w)], col[bidx(S, 2, slot, w)], col[bidx(S, 3, slot, w)]};
+}
+HSD void gst3(float *col, const SimState &S, int slot, int w, V3 v) {
+    col[bidx(S, 0, slot, w)] = v.x; col[bidx(S, 1, slot, w)] = v.y; col[bidx(S, 2, slot, w)] = v.z;
+}
+HSD void gst4(float *col, const SimState &S, int slot, int w, Q q) {
+    col[bidx(S, 0, slot, w)] = q.w; col[bidx(S, 1, slot, w)] = q.x; col[bidx(S, 2, slot, w)] = q.y; col[bidx(S, 3, slot, w)] = q.z;
+}
+HSD void gbody_load(const SimState &S, int w, int slot, BodyS &b) {
+    b.pos = gld3(S.bpos, S, slot, w); b.rot = gld4(S.brot, S, slot, w);
+    b.ppos = gld3(S.bppos, S, slot, w); b.prot = gld4(S.bprot, S, slot, w);
+    b.lin = gld3(S.blin, S, slot, w); b.ang = gld3(S.bang, S, slot, w);
+    const int m = S.bmeta[slot * S.N + w];
+    const bool dyn = m != 0 && meta_resp(m) == RESP_DYNAMIC;
+    b.invM = dyn ? obj_inv_mass(meta_obj(m)) : 0.f;
+    b.invI = dyn ? obj_inv_inertia(meta_obj(m)) : V3{0.f, 0.f, 0.f};
+}
+HSD void gbody_store_pose(const SimState &S, int w, int slot, const BodyS &b) { gst3(S.bpos, S, slot, w, b.pos); gst4(S.brot, S, slot, w, b.rot); }
+HSD void gbody_store_vel(const SimState &S, int w, int slot, const BodyS &b) { gst3(S.blin, S, slot, w, b.lin); gst3(S.bang, S, slot, w, b.ang); }
+HSD void derive_velocity(BodyS &b) {
+    const float h = kSubstepH;
+    b.lin = (b.pos - b.ppos) * (1.f / h);
+    Q dq = qmul(b.rot, qinv(b.prot));
+    V3 wv = V3{dq.x, dq.y, dq.z} * (2.f / h);
+    b.ang = dq.w >= 0.f ? wv : -wv;
+}
+
+// Append `value` to a global list for every lane with pred set: one atomic per wave
+// (wavefront ballot + prefix count).  Must be called by all lanes of the wave.
+HSD void wave_push(int *list, int *counter, int value, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// global ground-manifold word: np | vertex indices << 4 | hasStaticCandidates << 31
+constexpr int kGndHasWall = 1 << 30;
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N = S.N;
+    if (t == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }   // next substep's lists
+    if (t >= NS * N) return;
+    const int slot = t / N, w = t - slot * N;
+    if (slot == 0) {
+        S.ndd[w] = 0; S.nsc[w] = 0;
+        bool grab = false;
+        for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther[a * N + w] >= 0;
+        S.wflags[w] = grab ? 1 : 0;
+        if (grab) S.ddwList[atomicAdd(&S.counters[par * 4 + 2], 1)] = w;
+    }
+    const int meta = S.bmeta[slot * N + w];
+    if (meta == 0) return;
+    const int obj = meta_obj(meta);
+    V3 pos = gld3(S.bpos, S, slot, w); Q rot = gld4(S.brot, S, slot, w);
+    gst3(S.bppos, S, slot, w, pos); gst4(S.bprot, S, slot, w, rot);
+    if (meta_resp(meta) == RESP_DYNAMIC) {
+        const float h = kSubstepH;
+        V3 lin = gld3(S.blin, S, slot, w), ang = gld3(S.bang, S, slot, w);
+        const float invM = obj_inv_mass(obj);
+        const V3 invI = obj_inv_inertia(obj);
+        V3 force = {0.f, 0.f, 0.f}; float torque_z = 0.f;
+        if (slot >= kAgentSlot0) {
+            const int a = slot - kAgentSlot0;
+            force = {S.aforce[(0 * kMaxAgents + a) * N + w], S.aforce[(1 * kMaxAgents + a) * N + w], S.aforce[(2 * kMaxAgents + a) * N + w]};
+            torque_z = S.aforce[(3 * kMaxAgents + a) * N + w];
+        }
+        lin = lin + (force * invM + V3{0.f, 0.f, kGravityZ}) * h;
+        pos = pos + lin * h;
+        Q qi = qinv(rot);
+        V3 wl = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, torque_z});
+        V3 I = {invI.x > 0.f ? 1.f / invI.x : 0.f, invI.y > 0.f ? 1.f / invI.y : 0.f, invI.z > 0.f ? 1.f / invI.z : 0.f};
+        V3 Iw = mulc(I, wl);
+        wl = wl + mulc(invI, tl - cross(wl, Iw)) * h;
+        ang = qrot(rot, wl);
+        rot = quat_add_rotation(rot, ang * h);
+        gst3(S.bpos, S, slot, w, pos); gst4(S.brot, S, slot, w, rot);
+        gst3(S.blin, S, slot, w, lin); gst3(S.bang, S, slot, w, ang);
+    }
+    V3 lo, hi;
+    hull_aabb(hull_ref_body(obj, pos, rot), &lo, &hi);
+    gst3(S.blo, S, slot, w, lo); gst3(S.bhi, S, slot, w, hi);
+}
+
+// ------------------------------------------------------------------------------------------
+// World-major here (16 lanes per world, lane = body slot): the all-pairs AABB tests re-read every
+// wall and every other body's AABB, so the world's boxes are staged once in LDS.
+struct DetectWorld {
+    int meta[kNumDSlots];
+    float lo[kNumDSlots][3], hi[kNumDSlots][3];
+    float wall[kMaxWalls][4];
+    int ndd, nsc;
+};
+
+// Global list space is reserved with ONE atomic per list per 1024-thread block (a single counter
+// sustains only ~90 atomics/us, so per-wave reservations would dominate this kernel).
+__global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
+    constexpr int G = 16, NT = 1024, WPB = NT / G, NW = NT / 64;
+    __shared__ DetectWorld sh[WPB];
+    __shared__ int wtot[3][NW];
+    __shared__ int bbase[3];
+    const int tid = threadIdx.x, grp = tid / G, l = tid % G;
+    const int w = blockIdx.x * WPB + grp;
+    const int N = S.N;
+    const bool wok = w < N;
+    DetectWorld &dw = sh[grp];
+    int *cnt = S.counters + par * 4;
+    int nwl = 0, npl = 0;
+    if (wok) {
+        nwl = S.numWalls[w]; npl = S.numPlanes[w];
+        for (int s = l; s < kNumDSlots; s += G) {
+            const int m = s < NS ? S.bmeta[s * N + w] : 0;
+            dw.meta[s] = m;
+            if (m != 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { dw.lo[s][c] = S.blo[bidx(S, c, s, w)]; dw.hi[s][c] = S.bhi[bidx(S, c, s, w)]; }
+            }
+        }
+        for (int k = l; k < nwl; k += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dw.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
+        }
+        if (l == 0) { dw.ndd = 0; dw.nsc = 0; }
+    }
+    __syncthreads();
+    // a lane owns slot l (and slot 16 as lane 0's second body when 6 agents are configured)
+    int tot_items = 0;
+    unsigned dd_mask[2] = {0, 0}; unsigned long long s_mask[2] = {0ull, 0ull};
+    int bdd[2] = {0, 0}, bsc[2] = {0, 0}, add[2] = {0, 0}, asc[2] = {0, 0};
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const int slot = l + jb * G;
+        if (!wok || slot >= NS) continue;
+        const int meta = dw.meta[slot];
+        if (meta == 0) continue;
+        const bool dynamic = meta_resp(meta) == RESP_DYNAMIC;
+        const V3 lo = {dw.lo[slot][0], dw.lo[slot][1], dw.lo[slot][2]}, hi = {dw.hi[slot][0], dw.hi[slot][1], dw.hi[slot][2]};
+        for (int j = slot + 1; j < NS; ++j) {
+            const int mj = dw.meta[j];
+            if (mj == 0 || !(dynamic || meta_resp(mj) == RESP_DYNAMIC)) continue;
+            if (lo.x <= dw.hi[j][0] && dw.lo[j][0] <= hi.x && lo.y <= dw.hi[j][1] && dw.lo[j][1] <= hi.y &&
+                lo.z <= dw.hi[j][2] && dw.lo[j][2] <= hi.z) dd_mask[jb] |= 1u << j;
+        }
+        if (dynamic) {
+            for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
+            for (int k = 0; k < nwl; ++k) {
+                const float cx = dw.wall[k][0], cy = dw.wall[k][1], hx = dw.wall[k][2], hy = dw.wall[k][3];
+                if (lo.x <= cx + hx && cx - hx <= hi.x && lo.y <= cy + hy && cy - hy <= hi.y && lo.z <= 2.5f && 0.f <= hi.z)
+                    s_mask[jb] |= 1ull << k;
+            }
+        }
+        const int cdd = __popc(dd_mask[jb]), csc = __popcll(s_mask[jb]);
+        if (cdd) bdd[jb] = atomicAdd(&dw.ndd, cdd);
+        if (csc) bsc[jb] = atomicAdd(&dw.nsc, csc);
+        add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
+        asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
+        tot_items += add[jb] + asc[jb];
+    }
+    // ---- reserve space in the three global work lists: wave scans, block scan, one atomic per list
+    const int lane = tid & 63, wv = tid >> 6;
+    bool push_ddw = false;
+    int n_wall = 0;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) { push_ddw |= add[jb] > 0 && bdd[jb] == 0; n_wall += asc[jb] > 0 ? 1 : 0; }
+    push_ddw = push_ddw && wok && S.wflags[w] == 0;
+    int mine[3] = {tot_items, n_wall, push_ddw ? 1 : 0};
+    int incl[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int x = mine[q];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        incl[q] = x;
+        if (lane == 63) wtot[q][wv] = x;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        int tot = 0;
+        for (int k = 0; k < NW; ++k) { const int c = wtot[tid][k]; wtot[tid][k] = tot; tot += c; }
+        bbase[tid] = tot > 0 ? atomicAdd(&cnt[tid], tot) : 0;
+    }
+    __syncthreads();
+    int gbase = bbase[0] + wtot[0][wv] + incl[0] - mine[0];
+    int wbase2 = bbase[1] + wtot[1][wv] + incl[1] - mine[1];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const int slot = l + jb * G;
+        unsigned mm = dd_mask[jb]; int i = 0;
+        while (mm && i < add[jb]) {
+            const int j = __ffs(mm) - 1; mm &= mm - 1;
+            S.ddPair[(bdd[jb] + i) * N + w] = slot | (j << 8);
+            S.satList[gbase++] = (w << 6) | (bdd[jb] + i);
+            ++i;
+        }
+        unsigned long long sm = s_mask[jb]; i = 0;
+        while (sm && i < asc[jb]) {
+            const int k = __ffsll((long long)sm) - 1; sm &= sm - 1;
+            S.scPair[(bsc[jb] + i) * N + w] = slot | (k << 8);
+            S.satList[gbase++] = (w << 6) | 32 | (bsc[jb] + i);
+            ++i;
+        }
+        if (asc[jb] > 0) S.wallList[wbase2++] = (w << 5) | slot;
+    }
+    if (push_ddw) S.ddwList[bbase[2] + wtot[2][wv] + incl[2] - 1] = w;
+    __syncthreads();
+    if (wok && l == 0) { S.ndd[w] = dw.ndd; S.nsc[w] = dw.nsc; }
+    // ---- ground plane (plane 0) manifold of the owned bodies
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const int slot = l + jb * G;
+        if (!wok || slot >= NS) continue;
+        const int meta = dw.meta[slot];
+        if (meta == 0) continue;
+        int gword = asc[jb] > 0 ? kGndHasWall : 0;
+        if (meta_resp(meta) == RESP_DYNAMIC && npl >= 1) {
+            const int obj = meta_obj(meta);
+            HullRef hb = hull_ref_body(obj, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w));
+            RawManifold raw;
+            const V3 pn = {S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
+            if (collide_hull_plane(hb, pn, S.planes[(3 * kMaxPlanes) * N + w], raw)) {
+                gword |= raw.np;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < raw.np) { gword |= raw.vidx[j] << (4 + 3 * j); S.goff[bidx(S, j, slot, w)] = dot(raw.pB[j], raw.n); }
+                    S.glam[bidx(S, j, slot, w)] = 0.f;
+                }
+            }
+        }
+        S.gman[slot * N + w] = gword;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_sat(SimState S, int par) {
+    __shared__ ClipBuf clipbuf[64];
+    const int N = S.N;
+    const int total = S.counters[par * 4 + 0];
+    ClipBuf &cb = clipbuf[threadIdx.x];
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
+        const int item = S.satList[it];
+        const int w = item >> 6, idx = item & 63;
+        const bool isdd = idx < 32;
+        const int kk = idx & 31;
+        const int pair = isdd ? S.ddPair[kk * N + w] : S.scPair[kk * N + w];
+        const int a = pair & 0xff, bsel = pair >> 8;
+        ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
+        ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
+        const int oa = meta_obj(S.bmeta[a * N + w]);
+        const V3 pa = gld3(S.bpos, S, a, w);
+        const Q qa = gld4(S.brot, S, a, w);
+        const HullRef ha = hull_ref_body(oa, pa, qa);
+        RawManifold raw;
+        if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0;
+        if (!isdd && bsel >= kMaxWalls) {
+            const int p = bsel - kMaxWalls;
+            const V3 pn = {S.planes[(0 * kMaxPlanes + p) * N + w], S.planes[(1 * kMaxPlanes + p) * N + w], S.planes[(2 * kMaxPlanes + p) * N + w]};
+            if (collide_hull_plane(ha, pn, S.planes[(3 * kMaxPlanes + p) * N + w], raw)) {
+                ManS m;
+                m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
+                m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
+                m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = j < raw.np;
+                    st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
+                    m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
+                }
+                wsSC[kk] = m;
+            }
+            continue;
+        }
+        int ob; V3 pb = {0.f, 0.f, 0.f}; Q qb = {1.f, 0.f, 0.f, 0.f};
+        HullRef hb;
+        if (isdd) {
+            ob = meta_obj(S.bmeta[bsel * N + w]); pb = gld3(S.bpos, S, bsel, w); qb = gld4(S.brot, S, bsel, w);
+            hb = hull_ref_body(ob, pb, qb);
+        } else {
+            ob = OBJ_WALL;
+            hb = hull_ref_wall(S.walls[(0 * kMaxWalls + bsel) * N + w], S.walls[(1 * kMaxWalls + bsel) * N + w],
+                               S.walls[(2 * kMaxWalls + bsel) * N + w], S.walls[(3 * kMaxWalls + bsel) * N + w]);
+        }
+        if (!collide_hulls(ha, hb, cb, raw)) continue;
+        const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
+        const Q qai = qinv(qa);
+        if (isdd) {
+            ManDD m;
+            m.a = a; m.b = bsel; m.np = raw.np; m.muS = muS; m.muD = muD;
+            st3(m.n, raw.n);
+            const Q qbi = qinv(qb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = j < raw.np;
+                st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
+                m.lam[j] = 0.f;
+            }
+            wsDD[kk] = m;
+        } else {
+            ManS m;
+            m.np = raw.np; m.muS = muS; m.muD = muD; m.pad[0] = 0.f; m.pad[1] = 0.f;
+            st3(m.n, raw.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = j < raw.np;
+                st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
+            }
+            wsSC[kk] = m;
+        }
+    }
+}
+
+// Fixed grab joint on two loaded bodies (sim.cpp:343-356): angular alignment, then anchor coincidence.
+HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep) {
+    {
+        Q qa = qmul(A.rot, Q{1.f, 0.f, 0.f, 0.f}), qb = qmul(B.rot, attach2);
+        Q dq = qmul(qa, qinv(qb));
+        V3 dphi = {2.f * dq.x, 2.f * dq.y, 2.f * dq.z};
+        if (dq.w < 0.f) dphi = -dphi;
+        float th2 = len2(dphi);
+        if (th2 > 1e-12f) {
+            float th = sqrtf(th2);
+            V3 ax = dphi * (1.f / th);
+            V3 la = qrot(qinv(A.rot), ax), lb = qrot(qinv(B.rot), ax);
+            float wA = (la.x * la.x * A.invI.x + la.y * la.y * A.invI.y) + la.z * la.z * A.invI.z;
+            float wB = (lb.x * lb.x * B.invI.x + lb.y * lb.y * B.invI.y) + lb.z * lb.z * B.invI.z;
+            float ws = wA + wB;
+            if (ws > 0.f) {
+                V3 p = ax * (th / ws);
+                A.rot = quat_add_rotation(A.rot, -apply_inv_inertia(A.rot, A.invI, p));
+                B.rot = quat_add_rotation(B.rot, apply_inv_inertia(B.rot, B.invI, p));
+            }
+        }
+    }
+    {
+        V3 anchorA = V3{0.f, 1.25f, 0.5f} + V3{0.f, sep, 0.f};
+        V3 rAw = qrot(A.rot, anchorA), rBw = qrot(B.rot, r2);
+        V3 dx = (A.pos + rAw) - (B.pos + rBw);
+        float c2 = len2(dx);
+        if (c2 > 1e-12f) {
+            float c = sqrtf(c2);
+            V3 n = dx * (1.f / c);
+            float ws = gen_inv_mass(A.rot, A.invM, A.invI, rAw, n) + gen_inv_mass(B.rot, B.invM, B.invI, rBw, n);
+            if (ws > 0.f) apply_pos_impulse<true>(A, rAw, B, rBw, n * (c / ws));
+        }
+    }
+}
+
+// next body-body candidate index in increasing (a, b) key order after `last`; -1 when done
+HSD int next_sorted(const int *pairs, int N, int w, int n, int last_key, int *key_out) {
+    int best = -1, bk = 0x7fffffff;
+    for (int k = 0; k < n; ++k) {
+        const int p = pairs[k * N + w];
+        const int key = ((p & 0xff) << 8) | (p >> 8);
+        if (key > last_key && key < bk) { bk = key; best = k; }
+    }
+    *key_out = bk;
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_dd_pos(SimState S, int par) {
+    const int N = S.N;
+    const int total = S.counters[par * 4 + 2];
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
+        const int w = S.ddwList[it];
+        if (S.wflags[w]) {
+            const int teams = S.teams[w];
+            for (int a = 0; a < kMaxAgents; ++a) {
+                if (!team_agent_active(teams, a)) continue;
+                const int other = S.grabOther[a * N + w];
+                if (other < 0) continue;
+                BodyS A, B;
+                gbody_load(S, w, kAgentSlot0 + a, A); gbody_load(S, w, other, B);
+                float gd[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gd[c] = S.grabData[(c * kMaxAgents + a) * N + w];
+                solve_grab_joint_bodies(A, B, {gd[0], gd[1], gd[2]}, {gd[3], gd[4], gd[5], gd[6]}, gd[7]);
+                gbody_store_pose(S, w, kAgentSlot0 + a, A); gbody_store_pose(S, w, other, B);
+            }
+        }
+        ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
+        const int ndd = S.ndd[w] < kMaxDDCand ? S.ndd[w] : kMaxDDCand;
+        int last = -1;
+        for (int c = 0; c < ndd; ++c) {
+            int key;
+            const int k = next_sorted(S.ddPair, N, w, ndd, last, &key);
+            if (k < 0) break;
+            last = key;
+            if (wsDD[k].np <= 0) continue;
+            ManDD m = wsDD[k];                      // whole manifold in one burst of dwordx4 loads
+            BodyS Ab, Bb;
+            gbody_load(S, w, m.a, Ab); gbody_load(S, w, m.b, Bb);
+            const V3 n = ld3(m.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < m.np) wsDD[k].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+            gbody_store_pose(S, w, m.a, Ab); gbody_store_pose(S, w, m.b, Bb);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_dd_vel(SimState S, int par) {
+    const int N = S.N;
+    const int total = S.counters[par * 4 + 2];
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
+        const int w = S.ddwList[it];
+        ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
+        const int ndd = S.ndd[w] < kMaxDDCand ? S.ndd[w] : kMaxDDCand;
+        int last = -1;
+        for (int c = 0; c < ndd; ++c) {
+            int key;
+            const int k = next_sorted(S.ddPair, N, w, ndd, last, &key);
+            if (k < 0) break;
+            last = key;
+            if (wsDD[k].np <= 0) continue;
+            const ManDD m = wsDD[k];
+            BodyS Ab, Bb;
+            gbody_load(S, w, m.a, Ab); gbody_load(S, w, m.b, Bb);
+            const V3 n = ld3(m.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
+            gbody_store_vel(S, w, m.a, Ab); gbody_store_vel(S, w, m.b, Bb);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ground_pos(SimState S, int NS) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N = S.N;
+    if (t >= NS * N) return;
+    const int slot = t / N, w = t - slot * N;
+    const int meta = S.bmeta[slot * N + w];
+    if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
+    const int gword = S.gman[slot * N + w];
+    const int np = gword & 7;
+    const bool has_wall = (gword & kGndHasWall) != 0;
+    if (np == 0 && has_wall) return;          // nothing to do here; k_walls_pos derives the velocity
+    const int obj = meta_obj(meta);
+    BodyS me, none;
+    gbody_load(S, w, slot, me);
+    if (np > 0) {
+        const V3 gn = -V3{S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
+        const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+#pragma unroll 1
+        for (int j = 0; j < np; ++j) {
+            const float lam = solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (gword >> (4 + 3 * j)) & 7),
+                                                          V3{0.f, 0.f, 0.f}, S.goff[bidx(S, j, slot, w)], gmuS);
+            S.glam[bidx(S, j, slot, w)] += lam;
+        }
+        gbody_store_pose(S, w, slot, me);
+    }
+    if (!has_wall) { derive_velocity(me); gbody_store_vel(S, w, slot, me); }
+}
+
+__global__ void __launch_bounds__(256) k_ground_vel(SimState S, int NS) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N = S.N;
+    if (t >= NS * N) return;
+    const int slot = t / N, w = t - slot * N;
+    const int meta = S.bmeta[slot * N + w];
+    if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
+    const int gword = S.gman[slot * N + w];
+    const int np = gword & 7;
+    if (np == 0) return;
+    const int obj = meta_obj(meta);
+    BodyS me, none;
+    gbody_load(S, w, slot, me);
+    const V3 gn = -V3{S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
+    const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+#pragma unroll 1
+    for (int j = 0; j < np; ++j)
+        solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (gword >> (4 + 3 * j)) & 7), V3{0.f, 0.f, 0.f},
+                                    S.glam[bidx(S, j, slot, w)], gmuD);
+    gbody_store_vel(S, w, slot, me);
+}
+
+// next static candidate of `slot` in increasing static-id order after `last`; -1 when done
+HSD int next_static(const int *pairs, int N, int w, int n, int slot, int last_st, int *st_out) {
+    int best = -1, bs = 0x7fffffff;
+    for (int k = 0; k < n; ++k) {
+        const int p = pairs[k * N + w];
+        if ((p & 0xff) != slot) continue;
+        const int st = p >> 8;
+        // oracle order: planes 1.. first, then walls by index
+        const int key = st >= kMaxWalls ? st - kMaxWalls : st + kMaxPlanes;
+        if (key > last_st && key < bs) { bs = key; best = k; }
+    }
+    *st_out = bs;
+    return best;
+}
+
+__global__ void __launch_bounds__(64) k_walls_pos(SimState S, int par) {
+    const int N = S.N;
+    const int total = S.counters[par * 4 + 1];
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
+        const int item = S.wallList[it];
+        const int w = item >> 5, slot = item & 31;
+        ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
+        const int nsc = S.nsc[w] < kMaxSCand ? S.nsc[w] : kMaxSCand;
+        BodyS me, none;
+        gbody_load(S, w, slot, me);
+        int last = -1;
+        for (int c = 0; c < nsc; ++c) {
+            int key;
+            const int k = next_static(S.scPair, N, w, nsc, slot, last, &key);
+            if (k < 0) break;
+            last = key;
+            if (wsSC[k].np <= 0) continue;
+            ManS m = wsSC[k];
+            const V3 n = ld3(m.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < m.np) wsSC[k].lam[j] = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+        }
+        derive_velocity(me);
+        gbody_store_pose(S, w, slot, me); gbody_store_vel(S, w, slot, me);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_walls_vel(SimState S, int par) {
+    const int N = S.N;
+    const int total = S.counters[par * 4 + 1];
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
+        const int item = S.wallList[it];
+        const int w = item >> 5, slot = item & 31;
+        const ManS *const wsSC = (const ManS *)S.wsSC + (size_t)w * kMaxSCand;
+        const int nsc = S.nsc[w] < kMaxSCand ? S.nsc[w] : kMaxSCand;
+        BodyS me, none;
+        gbody_load(S, w, slot, me);
+        int last = -1;
+        for (int c = 0; c < nsc; ++c) {
+            int key;
+            const int k = next_static(S.scPair, N, w, nsc, slot, last, &key);
+            if (k < 0) break;
+            last = key;
+            if (wsSC[k].np <= 0) continue;
+            const ManS m = wsSC[k];
+            const V3 n = ld3(m.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
+        }
+        gbody_store_vel(S, w, slot, me);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Before the substeps: movementSystem | instantMovementSystem (sim.cpp:202-254) and actionSystem
+// (:270-370).  One 16-lane group per world; the world is staged in LDS only when an agent
+// actually locks or grabs (needs ray casts), which scripts/benchmark.py never does.
+__global__ void __launch_bounds__(256) k_pre(SimState S) {
+    constexpr int G = 16, WPB = 256 / G;
+    __shared__ ActWorld sh[WPB];
+    const int tid = threadIdx.x, grp = tid / G, l = tid % G;
+    const int w = blockIdx.x * WPB + grp;
+    const int N = S.N, A_ = S.A;
+    const bool wok = w < N;
+    ActWorld &pw = sh[grp];
+    const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
+    int teams = 0, step = 0;
+    if (wok) { teams = S.teams[w]; step = S.curEpisodeStep[w]; }
+    bool need_action = false;
+    if (wok && l < A_) {
+        const int agent = l;
+        const bool active = team_agent_active(teams, agent) != 0;
+        const int type = team_agent_type(teams, agent);
+        pw.actGL[agent] = 0;
+        if (active && !(type == AGENT_SEEKER && step < kNumPrepSteps - 1)) {
+            int32_t *act_row = S.xAction + (w * A_ + agent) * 5;
+            const int ax = act_row[0], ay = act_row[1], ar = act_row[2], ag = act_row[3], al = act_row[4];
+            float fx, fy, tz;
+            if (instant) { fx = 400.f * (float)(ax - 2); fy = 400.f * (float)(ay - 2); tz = 120.f * (float)(ar - 2); }
+            else { fx = 12.f * (float)(ax - 5); fy = 12.f * (float)(ay - 5); tz = 3.f * (float)(ar - 5); }
+            V3 f = qrot(gld4(S.brot, S, kAgentSlot0 + agent, w), {fx, fy, 0.f});
+            S.aforce[(0 * kMaxAgents + agent) * N + w] = f.x; S.aforce[(1 * kMaxAgents + agent) * N + w] = f.y;
+            S.aforce[(2 * kMaxAgents + agent) * N + w] = f.z; S.aforce[(3 * kMaxAgents + agent) * N + w] = tz;
+            const int fl = (ag == 1 ? 1 : 0) | (al == 1 ? 2 : 0);
+            pw.actGL[agent] = fl;
+            need_action = fl != 0;
+            act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;   // sim.cpp:365-369
+        }
+    }
+    // any lock/grab request in this block?  (block-uniform decision so the barriers below are safe)
+    const int any = __syncthreads_or(need_action ? 1 : 0);
+    if (!any) return;
+    if (wok) {
+        for (int s = l; s < kNumDSlots; s += G) {
+            pw.g.meta[s] = S.bmeta[s * N + w];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pw.g.pos[s][c] = S.bpos[(c * kNumDSlots + s) * N + w];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.g.rot[s][c] = S.brot[(c * kNumDSlots + s) * N + w];
+        }
+        const int nw = S.numWalls[w], npl = S.numPlanes[w];
+        for (int k = l; k < nw; k += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.g.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
+        }
+        for (int p = l; p < npl; p += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pw.g.plane[p][c] = S.planes[(c * kMaxPlanes + p) * N + w];
+        }
+        for (int i = l; i < kMaxAgents; i += G) {
+            pw.grabOther[i] = S.grabOther[i * N + w];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) pw.grabData[i][c] = S.grabData[(c * kMaxAgents + i) * N + w];
+            if (i >= A_) pw.actGL[i] = 0;
+        }
+        if (l == 0) { pw.g.numWalls = nw; pw.g.numPlanes = npl; pw.teams = teams; }
+    }
+    __syncthreads();
+    if (wok && l == 0) action_system(pw, A_);
+    __syncthreads();
+    if (wok) {
+        for (int s = l; s < kNumDSlots; s += G) S.bmeta[s * N + w] = pw.g.meta[s];
+        for (int i = l; i < kMaxAgents; i += G) {
+            S.grabOther[i * N + w] = pw.grabOther[i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) S.grabData[(c * kMaxAgents + i) * N + w] = pw.grabData[i][c];
+        }
+    }
+}
+
+// After the substeps: agentZeroVelSystem (sim.cpp:258-268), rewardsVisSystem (:763-804),
+// outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893).
+__global__ void __launch_bounds__(256) k_post(SimState S) {
+    constexpr int G = 16, WPB = 256 / G;
+    __shared__ WorldGeom sh[WPB];
+    __shared__ int seen_flag[WPB];
+    const int tid = threadIdx.x, grp = tid / G, l = tid % G;
+    const int w = blockIdx.x * WPB + grp;
+    const int N = S.N, A_ = S.A;
+    const bool wok = w < N;
+    WorldGeom &g = sh[grp];
+    const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
+    int teams = 0, step = 0, counts = 0;
+    if (wok) {
+        teams = S.teams[w]; step = S.curEpisodeStep[w]; counts = S.counts[w];
+        for (int s = l; s < kNumDSlots; s += G) {
+            g.meta[s] = S.bmeta[s * N + w];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g.pos[s][c] = S.bpos[(c * kNumDSlots + s) * N + w];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g.rot[s][c] = S.brot[(c * kNumDSlots + s) * N + w];
+        }
+        const int nw = S.numWalls[w], npl = S.numPlanes[w];
+        for (int k = l; k < nw; k += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
+        }
+        for (int p = l; p < npl; p += G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g.plane[p][c] = S.planes[(c * kMaxPlanes + p) * N + w];
+        }
+        if (l == 0) { g.numWalls = nw; g.numPlanes = npl; seen_flag[grp] = 0; }
+        if (instant && l < kMaxAgents && S.bmeta[(kAgentSlot0 + l) * N + w] != 0) {
+            const int slot = kAgentSlot0 + l;
+            S.blin[bidx(S, 0, slot, w)] = 0.f; S.blin[bidx(S, 1, slot, w)] = 0.f;
+            S.blin[bidx(S, 2, slot, w)] = fminf(S.blin[bidx(S, 2, slot, w)], 0.f);
+            gst3(S.bang, S, slot, w, V3{0.f, 0.f, 0.f});
+        }
+    }
+    __syncthreads();
+    if (wok && l < 9) {
+        const int si = l / 3, hi_ = l % 3;
+        if (si < cnt_seekers(counts) && hi_ < cnt_hiders(counts)) {
+            const int ss = kAgentSlot0 + team_seeker(teams, si), hs_ = kAgentSlot0 + team_hider(teams, hi_);
+            const V3 spos = geom_pos(g, ss);
+            const V3 fwd = qrot(geom_rot(g, ss), {0.f, 1.f, 0.f});
+            V3 to = geom_pos(g, hs_) - spos;
+            float c = dot(normalize(to), fwd);
+            if (!(c < kCosFovHalf)) {
+                float t;
+                if (trace_ray(g, spos, to, 1.f, &t) == hs_) seen_flag[grp] = 1;   // every writer stores the same value
+            }
+        }
+    }
+    __syncthreads();
+    if (!wok) return;
+    float hider_reward = S.hiderTeamReward[w];
+    if (seen_flag[grp]) hider_reward = -1.f;
+    if (l < A_ && team_agent_active(teams, l)) {
+        const int agent = l, slot = kAgentSlot0 + agent, row = w * A_ + agent;
+        if (step == 0) S.xDone[row] = 0;
+        if (step < kNumPrepSteps - 1) {
+            S.xReward[row] = 0.f;
+        } else {
+            if (step == kEpisodeLen - 1) S.xDone[row] = 1;
+            float r = hider_reward;
+            if (team_agent_type(teams, agent) == AGENT_SEEKER) r *= -1.f;
+            if (fabsf(g.pos[slot][0]) >= 18.f || fabsf(g.pos[slot][1]) >= 18.f) r -= 10.f;
+            S.xReward[row] = r;
+        }
+    }
+    if (l == 0) {
+        float *res = S.xEpisodeResult + w * 2;
+        int s0 = S.runningScores[0 * N + w], s1 = S.runningScores[1 * N + w];
+        if (step == 0) { res[0] = 0.f; res[1] = 0.f; s0 = 0; s1 = 0; }
+        if (step >= kNumPrepSteps) {
+            const bool hidden = hider_reward == 1.f;
+            const bool sf = cnt_seekers_first(counts) != 0;
+            const int win = hidden ? (sf ? 1 : 0) : (sf ? 0 : 1);
+            if (win == 0) s0 += 1; else s1 += 1;
+        }
+        if (step == kEpisodeLen - 1) {
+            if (s0 > s1) { res[0] = 1.f; res[1] = 0.f; }
+            else if (s0 < s1) { res[0] = 0.f; res[1] = 1.f; }
+            else { res[0] = 0.5f; res[1] = 0.5f; }
+        }
+        S.runningScores[0 * N + w] = s0; S.runningScores[1 * N + w] = s1;
+        S.hiderTeamReward[w] = hider_reward;
+    }
+}
+
+}  // namespace hs

@@ -49,8 +49,17 @@ struct SimState {
     int32_t *xReset, *xPrep, *xAction, *xSelfType, *xSeed, *xDone, *xPolicy;
     float *xSelfObs, *xSelfMask, *xAgentObs, *xBoxObs, *xRampObs, *xVisAgents, *xVisBoxes, *xVisRamps;
     float *xLidar, *xReward, *xGlobalPos, *xEpisodeResult;
-    // --- contact-manifold workspace (k_physics): [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
-    void *wsDD, *wsSC;
+    // --- substep scratch of the physics pipeline (hs_k_pipeline.h), all SoA across worlds
+    float *bppos, *bprot;  // [3][17][N], [4][17][N]  pose at the start of the substep
+    float *blo, *bhi;      // [3][17][N]  hull AABBs
+    int *gman;             // [17][N]     ground manifold: np | vertex ids << 4 | has-static-candidates << 30
+    float *goff, *glam;    // [4][17][N]  ground manifold plane offsets / accumulated multipliers
+    int *ndd, *nsc;        // [N]         candidate counts
+    int *ddPair, *scPair;  // [kMaxDDCand][N] a | b << 8 ; [kMaxSCand][N] body | static << 8
+    int *wflags;           // [N]         1 = world has a grab joint
+    void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
+    int *satList, *wallList, *ddwList;   // global work lists of one substep
+    int *counters;         // [2][4] list lengths (sat, wall, ddw), double-buffered by substep parity
     unsigned long long *dbg;   // [16] developer-only phase-cycle sums (HS_PHASE_TIMING builds)
 };
 

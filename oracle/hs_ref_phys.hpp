@@ -23,8 +23,8 @@ constexpr float kGravityZ = -9.8f;            // sim.cpp:1360
 // Candidate-pair capacities per world per substep (pairs whose AABBs overlap; measured maxima on
 // the benchmark workload are 6 accepted body-body and 9 accepted body-wall manifolds).  Pairs
 // beyond the capacity are dropped in pair order, identically in the HIP kernels.
-constexpr int kMaxDDCand = 8;                 // body-body candidate pairs
-constexpr int kMaxSCand = 12;                 // body-(wall | plane>=1) candidate pairs
+constexpr int kMaxDDCand = 16;                 // body-body candidate pairs
+constexpr int kMaxSCand = 24;                 // body-(wall | plane>=1) candidate pairs
 constexpr float kMaxDepenVel = 3.f;         // m/s, rate limit for pre-existing overlap
 
 // mgr.cpp:476-559 — inverse mass and friction per SimObject

@@ -21,9 +21,10 @@ L.hs_debug_phase_cycles(sim._h, C.byref(out), 1)
 for _ in range(steps):
     sim.step(); torch.randint(-5, 5, move.shape, out=move, dtype=torch.int32, device=move.device)
 L.hs_debug_phase_cycles(sim._h, C.byref(out), 0)
-names = ["stage", "move+action", "P1 integrate+aabb", "P2 candidates", "P3a ground", "P3b SAT", "P4 DD pos (lane0)",
-         "P4/5 static pos+vel derive", "P6a DD vel (lane0)", "P6b static vel", "tail"]
-tot = sum(out[:11])
+names = ["stage", "move+action", "P1 integrate+aabb", "P2 candidates+lists", "P3a ground collide", "P3b SAT (packed)",
+         "P4a DD pos (packed)", "P4b ground pos", "P4c walls pos (packed)", "P5 derive + P6a DD vel", "P6b ground vel",
+         "P6c walls vel (packed)"]
+tot = sum(out[:12])
 for i, n in enumerate(names):
-    print(f"{n:28s} {out[i] / tot * 100:6.2f}%   {out[i] / (steps * ((N + 3) // 4)):10.0f} cycles/wave-step")
-print("total cycles/wave-step", tot / (steps * ((N + 3) // 4)))
+    print(f"{n:28s} {out[i] / tot * 100:6.2f}%   {out[i] / (steps * ((N + 7) // 8 * 2)):10.0f} cycles/wave-step")
+print("total cycles/wave-step", tot / (steps * ((N + 7) // 8 * 2)))
