@@ -131,13 +131,11 @@ int32_t hs_agents_per_world(const hs_sim *sim);
 int32_t hs_debug_dump_bodies(hs_sim *sim, float *bodies, int32_t *meta);
 int32_t hs_debug_dump_walls(hs_sim *sim, float *walls, int32_t *info);
 
-/* Seconds of device time spent in each kernel of the last `hs_step` (order: physics, reset, observe),
- * measured with HIP events on the simulator's stream when profiling was enabled. */
+/* Milliseconds of device time of the last `hs_step`, measured with HIP events on the launch stream when
+ * profiling is enabled: [0] the physics pipeline (k_pre, 4 x 9 substep kernels, k_post), [1] k_reset,
+ * [2] k_observe. */
 int32_t hs_set_profiling(hs_sim *sim, int32_t enabled);
 int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
-
-/* Developer-only: per-phase shader-clock sums of the physics kernel (all zero in release builds). */
-int32_t hs_debug_phase_cycles(hs_sim *sim, uint64_t out[16], int32_t reset);
 
 const char *hs_last_error(void);
 const char *hs_version(void);

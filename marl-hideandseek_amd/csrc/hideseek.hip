@@ -70,19 +70,22 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
         // movement + actionSystem, 4 XPBD substeps (9 kernels each), rewards / dones / episode results
         const int NS = hs::kAgentSlot0 + s->A;                 // body slots in use
         const dim3 gridBody((NS * N + 255) / 256), gridWorld((N + 15) / 16);
-        const int sparse = N / 64 < 64 ? 64 : (N / 64 > 2048 ? 2048 : N / 64);   // grid-stride grids of the packed kernels
+        // packed kernels: grid-stride, sized so the usual item counts (~2.3 pairs, ~1.5 wall bodies,
+        // ~0.3 body-body worlds per world) finish in a single pass
+        const int gw = (N + 63) / 64;
+        const dim3 gridSat(gw * 4), gridWall(gw * 3), gridDD(gw);
         hipLaunchKernelGGL(hs::k_pre, gridWorld, dim3(256), 0, strm, S);
         for (int sub = 0; sub < 4; ++sub) {
             const int par = sub & 1;
             hipLaunchKernelGGL(hs::k_integrate, gridBody, dim3(256), 0, strm, S, NS, par);
             hipLaunchKernelGGL(hs::k_detect, dim3((N + 63) / 64), dim3(1024), 0, strm, S, NS, par);
-            hipLaunchKernelGGL(hs::k_sat, dim3(sparse * 2), dim3(64), 0, strm, S, par);
-            hipLaunchKernelGGL(hs::k_dd_pos, dim3(sparse), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_sat, gridSat, dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_dd_pos, gridDD, dim3(64), 0, strm, S, par);
             hipLaunchKernelGGL(hs::k_ground_pos, gridBody, dim3(256), 0, strm, S, NS);
-            hipLaunchKernelGGL(hs::k_walls_pos, dim3(sparse), dim3(64), 0, strm, S, par);
-            hipLaunchKernelGGL(hs::k_dd_vel, dim3(sparse), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_walls_pos, gridWall, dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_dd_vel, gridDD, dim3(64), 0, strm, S, par);
             hipLaunchKernelGGL(hs::k_ground_vel, gridBody, dim3(256), 0, strm, S, NS);
-            hipLaunchKernelGGL(hs::k_walls_vel, dim3(sparse), dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_walls_vel, gridWall, dim3(64), 0, strm, S, par);
         }
         hipLaunchKernelGGL(hs::k_post, gridWorld, dim3(256), 0, strm, S);
     }
@@ -147,7 +150,6 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xBoxObs, R * 9 * 17); HS_ALLOC(S.xRampObs, R * 2 * 14); HS_ALLOC(S.xVisAgents, R * 5);
     HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
-    HS_ALLOC(S.dbg, 16);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
     HS_ALLOC(S.bppos, 3 * D * N); HS_ALLOC(S.bprot, 4 * D * N); HS_ALLOC(S.blo, 3 * D * N); HS_ALLOC(S.bhi, 3 * D * N);
     HS_ALLOC(S.gman, D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
@@ -321,14 +323,6 @@ int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
         m[0] = nw[w]; m[1] = np[w]; m[2] = (c >> 12) & 15; m[3] = (c >> 16) & 15; m[4] = c & 15; m[5] = (c >> 4) & 15;
         m[6] = step[w]; m[7] = (c >> 20) & 1;
     }
-    return HS_OK;
-}
-
-// developer-only: per-phase shader-clock sums of k_physics (zeros unless built with -DHS_PHASE_TIMING)
-int32_t hs_debug_phase_cycles(hs_sim *s, uint64_t out[16], int32_t reset) {
-    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
-    HS_HIP(hipMemcpy(out, s->S.dbg, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HS_HIP(hipMemset(s->S.dbg, 0, 16 * sizeof(uint64_t)));
     return HS_OK;
 }
 

@@ -147,19 +147,35 @@ struct RawManifold { V3 n; int np; V3 pA[4]; V3 pB[4]; int vidx[4]; };
 HSD float box_radius(const HullRef &h, V3 n) {
     return (fabsf(dot(n, h.ax)) * h.e.x + fabsf(dot(n, h.ay)) * h.e.y) + fabsf(dot(n, h.az)) * h.e.z;
 }
-HSD float support_min(const HullRef &h, V3 n) {
-    if (h.kind == HULL_BOX) return dot(n, h.c) - box_radius(h, n);
-    float s = dot(n, hull_v(h, 0));
+// The wedge's six world vertices, computed once per convex test (its supports walk them ~46 times).
+struct WedgeVerts { V3 v[6]; };
+HSD void wedge_verts(const HullRef &h, WedgeVerts &wv) {
 #pragma unroll
-    for (int i = 1; i < 6; ++i) s = fminf(s, dot(n, hull_v(h, i)));
+    for (int i = 0; i < 6; ++i) wv.v[i] = hull_v(h, i);
+}
+HSD float support_min(const HullRef &h, const WedgeVerts &wv, V3 n) {
+    if (h.kind == HULL_BOX) return dot(n, h.c) - box_radius(h, n);
+    float s = dot(n, wv.v[0]);
+#pragma unroll
+    for (int i = 1; i < 6; ++i) s = fminf(s, dot(n, wv.v[i]));
     return s;
 }
-HSD float support_max(const HullRef &h, V3 n) {
+HSD float support_max(const HullRef &h, const WedgeVerts &wv, V3 n) {
     if (h.kind == HULL_BOX) return dot(n, h.c) + box_radius(h, n);
-    float s = dot(n, hull_v(h, 0));
+    float s = dot(n, wv.v[0]);
 #pragma unroll
-    for (int i = 1; i < 6; ++i) s = fmaxf(s, dot(n, hull_v(h, i)));
+    for (int i = 1; i < 6; ++i) s = fmaxf(s, dot(n, wv.v[i]));
     return s;
+}
+// plane offset of face f: closed form for boxes, first loop vertex for the wedge
+HSD float hull_fd_w(const HullRef &h, const WedgeVerts &wv, int f, V3 fn) {
+    if (h.kind == HULL_WEDGE) {
+        const int i = wedge_face_idx(f, 0);       // 4, 4, 2, 1, 5
+        const V3 v = i == 4 ? wv.v[4] : (i == 2 ? wv.v[2] : (i == 1 ? wv.v[1] : wv.v[5]));
+        return dot(fn, v);
+    }
+    const float ei = (f >> 1) == 0 ? h.e.x : ((f >> 1) == 1 ? h.e.y : h.e.z);
+    return dot(fn, h.c) + ei;
 }
 
 // Hull vs plane pn.p = pd: up to the 4 deepest vertices below the plane.
@@ -204,14 +220,23 @@ HSD void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3 *c1, V3 *c2) {
     *c1 = p1 + d1 * s; *c2 = p2 + d2 * t;
 }
 
-// per-lane LDS scratch for polygon clipping: two ping-pong polygons of up to 8 vertices
-struct ClipBuf { float p[2][8][3]; };
-HSD V3 cb_get(const ClipBuf &b, int w, int i) { return {b.p[w][i][0], b.p[w][i][1], b.p[w][i][2]}; }
-HSD void cb_set(ClipBuf &b, int w, int i, V3 v) { b.p[w][i][0] = v.x; b.p[w][i][1] = v.y; b.p[w][i][2] = v.z; }
+// LDS scratch for polygon clipping: two ping-pong polygons of up to 8 vertices per lane, laid out
+// [buffer][vertex][component][lane] so that the 64 lanes of a wave hit 64 different banks (a
+// per-lane struct of 48 words would be a 16-way bank conflict on every access).
+constexpr int kClipWords = 2 * 8 * 3 * 64;
+struct ClipBuf { float *base; int lane; };
+HSD V3 cb_get(const ClipBuf &b, int w, int i) {
+    const float *p = b.base + ((w * 8 + i) * 3) * 64 + b.lane;
+    return {p[0], p[64], p[128]};
+}
+HSD void cb_set(const ClipBuf &b, int w, int i, V3 v) {
+    float *p = b.base + ((w * 8 + i) * 3) * 64 + b.lane;
+    p[0] = v.x; p[64] = v.y; p[128] = v.z;
+}
 
 // Clip the incident face of I against the side planes of reference face fr of R; keep points on
 // or below the reference plane; reduce to <= 4.  Returns the count; pInc/dist_out have 4 slots.
-HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, ClipBuf &cb, V3 *pInc, float *dist_out) {
+HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, const ClipBuf &cb, V3 *pInc, float *dist_out) {
     const float dr = hull_fd(R, fr, nr);
     const int inf = hull_nf(I);
     int fi = 0; float best = dot(nr, hull_fn(I, 0));
@@ -283,19 +308,22 @@ HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, Cli
     return 4;
 }
 
-HSD bool collide_hulls(const HullRef &A, const HullRef &B, ClipBuf &cb, RawManifold &m) {
+HSD bool collide_hulls(const HullRef &A, const HullRef &B, const ClipBuf &cb, RawManifold &m) {
+    WedgeVerts wa, wb;
+    if (A.kind == HULL_WEDGE) wedge_verts(A, wa);
+    if (B.kind == HULL_WEDGE) wedge_verts(B, wb);
     float bestA = 0.f; int fa = -1;
     const int anf = hull_nf(A), bnf = hull_nf(B);
     for (int f = 0; f < anf; ++f) {
         V3 fn = hull_fn(A, f);
-        float s = support_min(B, fn) - hull_fd(A, f, fn);
+        float s = support_min(B, wb, fn) - hull_fd_w(A, wa, f, fn);
         if (s > 0.f) return false;
         if (fa < 0 || s > bestA) { bestA = s; fa = f; }
     }
     float bestB = 0.f; int fb = -1;
     for (int f = 0; f < bnf; ++f) {
         V3 fn = hull_fn(B, f);
-        float s = support_min(A, fn) - hull_fd(B, f, fn);
+        float s = support_min(A, wa, fn) - hull_fd_w(B, wb, f, fn);
         if (s > 0.f) return false;
         if (fb < 0 || s > bestB) { bestB = s; fb = f; }
     }
@@ -310,7 +338,7 @@ HSD bool collide_hulls(const HullRef &A, const HullRef &B, ClipBuf &cb, RawManif
             if (l2 < 1e-6f) continue;
             ax = ax * (1.f / sqrtf(l2));
             if (dot(ax, ab) < 0.f) ax = -ax;
-            float s = support_min(B, ax) - support_max(A, ax);
+            float s = support_min(B, wb, ax) - support_max(A, wa, ax);
             if (s > 0.f) return false;
             if (ea < 0 || s > bestE) { bestE = s; ea = i; eb = j; axE = ax; }
         }

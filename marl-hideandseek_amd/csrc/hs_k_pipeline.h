@@ -276,10 +276,10 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_sat(SimState S, int par) {
-    __shared__ ClipBuf clipbuf[64];
+    __shared__ float clipmem[kClipWords];
     const int N = S.N;
     const int total = S.counters[par * 4 + 0];
-    ClipBuf &cb = clipbuf[threadIdx.x];
+    const ClipBuf cb = {clipmem, (int)threadIdx.x};
     for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
         const int item = S.satList[it];
         const int w = item >> 6, idx = item & 63;

@@ -60,7 +60,6 @@ struct SimState {
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
     int *satList, *wallList, *ddwList;   // global work lists of one substep
     int *counters;         // [2][4] list lengths (sat, wall, ddw), double-buffered by substep parity
-    unsigned long long *dbg;   // [16] developer-only phase-cycle sums (HS_PHASE_TIMING builds)
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }
