@@ -137,6 +137,10 @@ int32_t hs_debug_dump_walls(hs_sim *sim, float *walls, int32_t *info);
 int32_t hs_set_profiling(hs_sim *sim, int32_t enabled);
 int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
 
+/* Profiling aid: one dword-per-lane coalesced copy of `bytes` bytes (read + write), used to calibrate the
+ * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */
+int32_t hs_debug_calibrate(int64_t bytes);
+
 const char *hs_last_error(void);
 const char *hs_version(void);
 

@@ -326,6 +326,23 @@ int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
     return HS_OK;
 }
 
+// PMC calibration (MI355X_MICROARCH.md: FETCH_SIZE is uncalibrated for narrow accesses): copies `bytes`
+// with the access pattern of the simulator's SoA columns — one coalesced dword per lane.
+__global__ void k_calib_copy_dword(const float *in, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i] + 1.f;
+}
+int32_t hs_debug_calibrate(int64_t bytes) {
+    if (bytes <= 0) return fail(HS_ERR_INVALID_ARG, "bytes must be > 0");
+    float *a = nullptr, *b = nullptr;
+    HS_HIP(hipMalloc((void **)&a, (size_t)bytes));
+    HS_HIP(hipMalloc((void **)&b, (size_t)bytes));
+    HS_HIP(hipMemset(a, 0, (size_t)bytes));
+    hipLaunchKernelGGL(k_calib_copy_dword, dim3(4096), dim3(256), 0, nullptr, a, b, (size_t)bytes / 4);
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipFree(a)); HS_HIP(hipFree(b));
+    return HS_OK;
+}
+
 int32_t hs_set_profiling(hs_sim *s, int32_t enabled) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     s->profiling = enabled != 0;
