@@ -52,6 +52,7 @@ HSD void gbody_load(const SimState &S, int w, int slot, BodyS &b) {
     const bool dyn = m != 0 && meta_resp(m) == RESP_DYNAMIC;
     b.invM = dyn ? obj_inv_mass(meta_obj(m)) : 0.f;
     b.invI = dyn ? obj_inv_inertia(meta_obj(m)) : V3{0.f, 0.f, 0.f};
+    body_refresh_inertia(b);
 }
 HSD void gbody_store_pose(const SimState &S, int w, int slot, const BodyS &b) { gst3(S.bpos, S, slot, w, b.pos); gst4(S.brot, S, slot, w, b.rot); }
 HSD void gbody_store_vel(const SimState &S, int w, int slot, const BodyS &b) { gst3(S.blin, S, slot, w, b.lin); gst3(S.bang, S, slot, w, b.ang); }
@@ -365,14 +366,13 @@ HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep
         if (th2 > 1e-12f) {
             float th = sqrtf(th2);
             V3 ax = dphi * (1.f / th);
-            V3 la = qrot(qinv(A.rot), ax), lb = qrot(qinv(B.rot), ax);
-            float wA = (la.x * la.x * A.invI.x + la.y * la.y * A.invI.y) + la.z * la.z * A.invI.z;
-            float wB = (lb.x * lb.x * B.invI.x + lb.y * lb.y * B.invI.y) + lb.z * lb.z * B.invI.z;
+            float wA = dot(ax, sym_mul(A.Iw, ax));
+            float wB = dot(ax, sym_mul(B.Iw, ax));
             float ws = wA + wB;
             if (ws > 0.f) {
                 V3 p = ax * (th / ws);
-                A.rot = quat_add_rotation(A.rot, -apply_inv_inertia(A.rot, A.invI, p));
-                B.rot = quat_add_rotation(B.rot, apply_inv_inertia(B.rot, B.invI, p));
+                A.rot = quat_add_rotation(A.rot, -apply_inv_inertia(A, p));
+                B.rot = quat_add_rotation(B.rot, apply_inv_inertia(B, p));
             }
         }
     }
@@ -384,7 +384,7 @@ HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep
         if (c2 > 1e-12f) {
             float c = sqrtf(c2);
             V3 n = dx * (1.f / c);
-            float ws = gen_inv_mass(A.rot, A.invM, A.invI, rAw, n) + gen_inv_mass(B.rot, B.invM, B.invI, rBw, n);
+            float ws = gen_inv_mass(A, rAw, n) + gen_inv_mass(B, rBw, n);
             if (ws > 0.f) apply_pos_impulse<true>(A, rAw, B, rBw, n * (c / ws));
         }
     }
@@ -554,6 +554,7 @@ __global__ void __launch_bounds__(64) k_walls_pos(SimState S, int par) {
             last = key;
             if (wsSC[k].np <= 0) continue;
             ManS m = wsSC[k];
+            body_refresh_inertia(me);
             const V3 n = ld3(m.n);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -582,6 +583,7 @@ __global__ void __launch_bounds__(64) k_walls_vel(SimState S, int par) {
             last = key;
             if (wsSC[k].np <= 0) continue;
             const ManS m = wsSC[k];
+            body_refresh_inertia(me);
             const V3 n = ld3(m.n);
 #pragma unroll
             for (int j = 0; j < 4; ++j)

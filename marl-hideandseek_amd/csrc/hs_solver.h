@@ -24,22 +24,43 @@ struct ActWorld {
     int teams;
 };
 
-struct BodyS { V3 pos; Q rot; V3 ppos; Q prot; V3 lin, ang; float invM; V3 invI; };
+HSD bool has_mass_i(float invM, V3 invI) { return invM != 0.f || invI.z != 0.f || invI.x != 0.f || invI.y != 0.f; }
+
+// World-space inverse inertia R diag(invI) R^T (symmetric): evaluated once per manifold / joint from the
+// body's rotation at that moment and kept while the manifold's contact points are solved.
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+struct BodyS { V3 pos; Q rot; V3 ppos; Q prot; V3 lin, ang; float invM; V3 invI; Sym3 Iw; };
+
+HSD Sym3 world_inv_inertia(Q q, V3 invI) {
+    M3 m = m3_from_quat(q);
+    V3 r0 = m.c0 * invI.x, r1 = m.c1 * invI.y, r2 = m.c2 * invI.z;
+    Sym3 s;
+    s.xx = (r0.x * m.c0.x + r1.x * m.c1.x) + r2.x * m.c2.x;
+    s.xy = (r0.x * m.c0.y + r1.x * m.c1.y) + r2.x * m.c2.y;
+    s.xz = (r0.x * m.c0.z + r1.x * m.c1.z) + r2.x * m.c2.z;
+    s.yy = (r0.y * m.c0.y + r1.y * m.c1.y) + r2.y * m.c2.y;
+    s.yz = (r0.y * m.c0.z + r1.y * m.c1.z) + r2.y * m.c2.z;
+    s.zz = (r0.z * m.c0.z + r1.z * m.c1.z) + r2.z * m.c2.z;
+    return s;
+}
+HSD V3 sym_mul(const Sym3 &s, V3 v) {
+    return {(s.xx * v.x + s.xy * v.y) + s.xz * v.z, (s.xy * v.x + s.yy * v.y) + s.yz * v.z,
+            (s.xz * v.x + s.yz * v.y) + s.zz * v.z};
+}
+// call at the start of every manifold / joint (the oracle re-evaluates body_mass there)
+HSD void body_refresh_inertia(BodyS &b) {
+    b.Iw = has_mass_i(b.invM, b.invI) ? world_inv_inertia(b.rot, b.invI) : Sym3{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
 
 HSD V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
 HSD Q ld4(const float *p) { return {p[0], p[1], p[2], p[3]}; }
 HSD void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 HSD void st4(float *p, Q q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 
-HSD V3 apply_inv_inertia(Q q, V3 invI, V3 v) {
-    V3 l = qrot(qinv(q), v);
-    l = mulc(l, invI);
-    return qrot(q, l);
-}
-HSD float gen_inv_mass(Q q, float invM, V3 invI, V3 r, V3 n) {
+HSD V3 apply_inv_inertia(const BodyS &b, V3 v) { return sym_mul(b.Iw, v); }
+HSD float gen_inv_mass(const BodyS &b, V3 r, V3 n) {
     V3 rn = cross(r, n);
-    V3 l = qrot(qinv(q), rn);
-    return invM + ((l.x * l.x * invI.x + l.y * l.y * invI.y) + l.z * l.z * invI.z);
+    return b.invM + dot(rn, sym_mul(b.Iw, rn));
 }
 HSD Q quat_add_rotation(Q q, V3 dth) {
     Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
@@ -52,12 +73,12 @@ template <bool HAS_B>
 HSD void apply_pos_impulse(BodyS &A, V3 rA, BodyS &B, V3 rB, V3 p) {
     if (has_mass(A)) {
         A.pos = A.pos - p * A.invM;
-        V3 dth = apply_inv_inertia(A.rot, A.invI, cross(rA, p));
+        V3 dth = apply_inv_inertia(A, cross(rA, p));
         A.rot = quat_add_rotation(A.rot, -dth);
     }
     if (HAS_B && has_mass(B)) {
         B.pos = B.pos + p * B.invM;
-        V3 dth = apply_inv_inertia(B.rot, B.invI, cross(rB, p));
+        V3 dth = apply_inv_inertia(B, cross(rB, p));
         B.rot = quat_add_rotation(B.rot, dth);
     }
 }
@@ -78,8 +99,8 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
     float excess = dprev - kMaxDepenVel * kSubstepH;
     if (excess > 0.f) d = d - excess;
     if (!(d > 0.f)) return 0.f;
-    float wA = gen_inv_mass(A.rot, A.invM, A.invI, rAw, n);
-    float wB = HAS_B ? gen_inv_mass(B.rot, B.invM, B.invI, rBw, n) : 0.f;
+    float wA = gen_inv_mass(A, rAw, n);
+    float wB = HAS_B ? gen_inv_mass(B, rBw, n) : 0.f;
     float wsum = wA + wB;
     if (!(wsum > 0.f)) return 0.f;
     float lam = d / wsum;
@@ -99,8 +120,8 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
     if (lt2 > 1e-12f) {
         float lt = sqrtf(lt2);
         V3 t = dpt * (1.f / lt);
-        float wtA = gen_inv_mass(A.rot, A.invM, A.invI, rAw, t);
-        float wtB = HAS_B ? gen_inv_mass(B.rot, B.invM, B.invI, rBw, t) : 0.f;
+        float wtA = gen_inv_mass(A, rAw, t);
+        float wtB = HAS_B ? gen_inv_mass(B, rBw, t) : 0.f;
         float wts = wtA + wtB;
         if (wts > 0.f) {
             float lamT = lt / wts;
@@ -132,16 +153,16 @@ HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float la
     float dvl = len(dv);
     if (!(dvl > 1e-9f)) return;
     V3 dir = dv * (1.f / dvl);
-    float wA = gen_inv_mass(A.rot, A.invM, A.invI, rAw, dir);
-    float wB = HAS_B ? gen_inv_mass(B.rot, B.invM, B.invI, rBw, dir) : 0.f;
+    float wA = gen_inv_mass(A, rAw, dir);
+    float wB = HAS_B ? gen_inv_mass(B, rBw, dir) : 0.f;
     float ws = wA + wB;
     if (!(ws > 0.f)) return;
     V3 p = dir * (dvl / ws);
     A.lin = A.lin + p * A.invM;
-    A.ang = A.ang + apply_inv_inertia(A.rot, A.invI, cross(rAw, p));
+    A.ang = A.ang + apply_inv_inertia(A, cross(rAw, p));
     if (HAS_B) {
         B.lin = B.lin - p * B.invM;
-        B.ang = B.ang - apply_inv_inertia(B.rot, B.invI, cross(rBw, p));
+        B.ang = B.ang - apply_inv_inertia(B, cross(rBw, p));
     }
 }
 

@@ -351,22 +351,37 @@ static inline bool collide_hulls(const Hull &A, const Hull &B, RawManifold &m) {
 // ----------------------------------------------------------------------------------------
 // XPBD solver
 // ----------------------------------------------------------------------------------------
-struct BodyMass { float invM; V3 invI; };
+// World-space inverse inertia R diag(invI) R^T (symmetric, 6 values).  It is evaluated once per
+// manifold (and per joint) from the body's rotation at that moment and kept while the manifold's
+// contact points are solved.
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+static inline Sym3 world_inv_inertia(Q q, V3 invI) {
+    M3 m = m3_from_quat(q);
+    V3 r0 = m.c0 * invI.x, r1 = m.c1 * invI.y, r2 = m.c2 * invI.z;
+    Sym3 s;
+    s.xx = (r0.x * m.c0.x + r1.x * m.c1.x) + r2.x * m.c2.x;
+    s.xy = (r0.x * m.c0.y + r1.x * m.c1.y) + r2.x * m.c2.y;
+    s.xz = (r0.x * m.c0.z + r1.x * m.c1.z) + r2.x * m.c2.z;
+    s.yy = (r0.y * m.c0.y + r1.y * m.c1.y) + r2.y * m.c2.y;
+    s.yz = (r0.y * m.c0.z + r1.y * m.c1.z) + r2.y * m.c2.z;
+    s.zz = (r0.z * m.c0.z + r1.z * m.c1.z) + r2.z * m.c2.z;
+    return s;
+}
+static inline V3 sym_mul(const Sym3 &s, V3 v) {
+    return {(s.xx * v.x + s.xy * v.y) + s.xz * v.z, (s.xy * v.x + s.yy * v.y) + s.yz * v.z,
+            (s.xz * v.x + s.yz * v.y) + s.zz * v.z};
+}
+struct BodyMass { float invM; V3 invI; Sym3 Iw; };
 
 static inline BodyMass body_mass(const DBody &b) {
-    if (b.objType == OBJ_NONE || b.response != RESP_DYNAMIC) return {0.f, {0.f, 0.f, 0.f}};
-    return {obj_inv_mass(b.objType), obj_inv_inertia(b.objType)};
+    if (b.objType == OBJ_NONE || b.response != RESP_DYNAMIC) return {0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    V3 invI = obj_inv_inertia(b.objType);
+    return {obj_inv_mass(b.objType), invI, world_inv_inertia(b.rot, invI)};
 }
-// world-space I^-1 * v for a diagonal body-frame tensor
-static inline V3 apply_inv_inertia(Q q, V3 invI, V3 v) {
-    V3 l = qrot(qinv(q), v);
-    l = mulc(l, invI);
-    return qrot(q, l);
-}
-static inline float gen_inv_mass(Q q, const BodyMass &bm, V3 r, V3 n) {
+static inline V3 apply_inv_inertia(const BodyMass &bm, V3 v) { return sym_mul(bm.Iw, v); }
+static inline float gen_inv_mass(const BodyMass &bm, V3 r, V3 n) {
     V3 rn = cross(r, n);
-    V3 l = qrot(qinv(q), rn);
-    return bm.invM + ((l.x * l.x * bm.invI.x + l.y * l.y * bm.invI.y) + l.z * l.z * bm.invI.z);
+    return bm.invM + dot(rn, sym_mul(bm.Iw, rn));
 }
 static inline Q quat_add_rotation(Q q, V3 dth) {     // q += 0.5 * (0,dth) * q ; normalize
     Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
@@ -378,12 +393,12 @@ static inline void apply_pos_impulse(DBody *A, const BodyMass &ma, V3 rA, DBody 
                                      V3 rB, V3 p) {
     if (ma.invM != 0.f || ma.invI.z != 0.f || ma.invI.x != 0.f || ma.invI.y != 0.f) {
         A->pos = A->pos - p * ma.invM;
-        V3 dth = apply_inv_inertia(A->rot, ma.invI, cross(rA, p));
+        V3 dth = apply_inv_inertia(ma, cross(rA, p));
         A->rot = quat_add_rotation(A->rot, -dth);
     }
     if (B && (mb.invM != 0.f || mb.invI.z != 0.f || mb.invI.x != 0.f || mb.invI.y != 0.f)) {
         B->pos = B->pos + p * mb.invM;
-        V3 dth = apply_inv_inertia(B->rot, mb.invI, cross(rB, p));
+        V3 dth = apply_inv_inertia(mb, cross(rB, p));
         B->rot = quat_add_rotation(B->rot, dth);
     }
 }
@@ -392,7 +407,7 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
     DBody *A = &w.d[m.a];
     DBody *B = m.b >= 0 ? &w.d[m.b] : nullptr;
     BodyMass ma = body_mass(*A);
-    BodyMass mb = B ? body_mass(*B) : BodyMass{0.f, {0.f, 0.f, 0.f}};
+    BodyMass mb = B ? body_mass(*B) : BodyMass{0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
     const V3 n = m.n;
     for (int j = 0; j < m.np; ++j) {
         V3 rAw = qrot(A->rot, m.rA[j]);
@@ -410,8 +425,8 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
         float excess = dprev - kMaxDepenVel * kSubstepH;
         if (excess > 0.f) d = d - excess;
         if (!(d > 0.f)) continue;
-        float wA = gen_inv_mass(A->rot, ma, rAw, n);
-        float wB = B ? gen_inv_mass(B->rot, mb, rBw, n) : 0.f;
+        float wA = gen_inv_mass(ma, rAw, n);
+        float wB = B ? gen_inv_mass(mb, rBw, n) : 0.f;
         float wsum = wA + wB;
         if (!(wsum > 0.f)) continue;
         float lam = d / wsum;
@@ -433,8 +448,8 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
         if (lt2 > 1e-12f) {
             float lt = sqrtf(lt2);
             V3 t = dpt * (1.f / lt);
-            float wtA = gen_inv_mass(A->rot, ma, rAw, t);
-            float wtB = B ? gen_inv_mass(B->rot, mb, rBw, t) : 0.f;
+            float wtA = gen_inv_mass(ma, rAw, t);
+            float wtB = B ? gen_inv_mass(mb, rBw, t) : 0.f;
             float wts = wtA + wtB;
             if (wts > 0.f) {
                 float lamT = lt / wts;
@@ -447,10 +462,10 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
 static inline void apply_vel_impulse(DBody *A, const BodyMass &ma, V3 rA, DBody *B, const BodyMass &mb,
                                      V3 rB, V3 p) {   // A gets +p, B gets -p
     A->lin = A->lin + p * ma.invM;
-    A->ang = A->ang + apply_inv_inertia(A->rot, ma.invI, cross(rA, p));
+    A->ang = A->ang + apply_inv_inertia(ma, cross(rA, p));
     if (B) {
         B->lin = B->lin - p * mb.invM;
-        B->ang = B->ang - apply_inv_inertia(B->rot, mb.invI, cross(rB, p));
+        B->ang = B->ang - apply_inv_inertia(mb, cross(rB, p));
     }
 }
 
@@ -459,7 +474,7 @@ static inline void solve_manifold_velocities(World &w, const Manifold &m) {
     DBody *A = &w.d[m.a];
     DBody *B = m.b >= 0 ? &w.d[m.b] : nullptr;
     BodyMass ma = body_mass(*A);
-    BodyMass mb = B ? body_mass(*B) : BodyMass{0.f, {0.f, 0.f, 0.f}};
+    BodyMass mb = B ? body_mass(*B) : BodyMass{0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
     const V3 n = m.n;
     for (int j = 0; j < m.np; ++j) {
         float lamN = m.lambdaN[j];
@@ -482,8 +497,8 @@ static inline void solve_manifold_velocities(World &w, const Manifold &m) {
         float dvl = len(dv);
         if (!(dvl > 1e-9f)) continue;
         V3 dir = dv * (1.f / dvl);
-        float wA = gen_inv_mass(A->rot, ma, rAw, dir);
-        float wB = B ? gen_inv_mass(B->rot, mb, rBw, dir) : 0.f;
+        float wA = gen_inv_mass(ma, rAw, dir);
+        float wB = B ? gen_inv_mass(mb, rBw, dir) : 0.f;
         float ws = wA + wB;
         if (!(ws > 0.f)) continue;
         apply_vel_impulse(A, ma, rAw, B, mb, rBw, dir * (dvl / ws));
@@ -507,14 +522,13 @@ static inline void solve_grab_joint(World &w, int agent) {
         if (th2 > 1e-12f) {
             float th = sqrtf(th2);
             V3 ax = dphi * (1.f / th);
-            V3 la = qrot(qinv(A->rot), ax), lb = qrot(qinv(B->rot), ax);
-            float wA = (la.x * la.x * ma.invI.x + la.y * la.y * ma.invI.y) + la.z * la.z * ma.invI.z;
-            float wB = (lb.x * lb.x * mb.invI.x + lb.y * lb.y * mb.invI.y) + lb.z * lb.z * mb.invI.z;
+            float wA = dot(ax, sym_mul(ma.Iw, ax));
+            float wB = dot(ax, sym_mul(mb.Iw, ax));
             float ws = wA + wB;
             if (ws > 0.f) {
                 V3 p = ax * (th / ws);
-                A->rot = quat_add_rotation(A->rot, -apply_inv_inertia(A->rot, ma.invI, p));
-                B->rot = quat_add_rotation(B->rot, apply_inv_inertia(B->rot, mb.invI, p));
+                A->rot = quat_add_rotation(A->rot, -apply_inv_inertia(ma, p));
+                B->rot = quat_add_rotation(B->rot, apply_inv_inertia(mb, p));
             }
         }
     }
@@ -526,7 +540,7 @@ static inline void solve_grab_joint(World &w, int agent) {
         if (c2 > 1e-12f) {
             float c = sqrtf(c2);
             V3 n = dx * (1.f / c);
-            float ws = gen_inv_mass(A->rot, ma, rAw, n) + gen_inv_mass(B->rot, mb, rBw, n);
+            float ws = gen_inv_mass(ma, rAw, n) + gen_inv_mass(mb, rBw, n);
             if (ws > 0.f) apply_pos_impulse(A, ma, rAw, B, mb, rBw, n * (c / ws));
         }
     }
