@@ -73,17 +73,17 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
         // packed kernels: grid-stride, sized so the usual item counts (~2.3 pairs, ~1.5 wall bodies,
         // ~0.3 body-body worlds per world) finish in a single pass
         const int gw = (N + 63) / 64;
-        const dim3 gridSat(gw * 4), gridWall(gw * 3), gridDD(gw);
+        const dim3 gridSat(gw * 4), gridWall(gw * 3), gridDD(gw * 4);      // k_dd: 8 lanes per world
         hipLaunchKernelGGL(hs::k_pre, gridWorld, dim3(256), 0, strm, S);
         for (int sub = 0; sub < 4; ++sub) {
             const int par = sub & 1;
             hipLaunchKernelGGL(hs::k_integrate, gridBody, dim3(256), 0, strm, S, NS, par);
             hipLaunchKernelGGL(hs::k_detect, dim3((N + 63) / 64), dim3(1024), 0, strm, S, NS, par);
             hipLaunchKernelGGL(hs::k_sat, gridSat, dim3(64), 0, strm, S, par);
-            hipLaunchKernelGGL(hs::k_dd_pos, gridDD, dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_dd<true>, gridDD, dim3(64), 0, strm, S, par);
             hipLaunchKernelGGL(hs::k_ground_pos, gridBody, dim3(256), 0, strm, S, NS);
             hipLaunchKernelGGL(hs::k_walls_pos, gridWall, dim3(64), 0, strm, S, par);
-            hipLaunchKernelGGL(hs::k_dd_vel, gridDD, dim3(64), 0, strm, S, par);
+            hipLaunchKernelGGL(hs::k_dd<false>, gridDD, dim3(64), 0, strm, S, par);
             hipLaunchKernelGGL(hs::k_ground_vel, gridBody, dim3(256), 0, strm, S, NS);
             hipLaunchKernelGGL(hs::k_walls_vel, gridWall, dim3(64), 0, strm, S, par);
         }

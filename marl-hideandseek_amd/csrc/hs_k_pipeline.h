@@ -390,25 +390,24 @@ HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep
     }
 }
 
-// next body-body candidate index in increasing (a, b) key order after `last`; -1 when done
-HSD int next_sorted(const int *pairs, int N, int w, int n, int last_key, int *key_out) {
-    int best = -1, bk = 0x7fffffff;
-    for (int k = 0; k < n; ++k) {
-        const int p = pairs[k * N + w];
-        const int key = ((p & 0xff) << 8) | (p >> 8);
-        if (key > last_key && key < bk) { bk = key; best = k; }
-    }
-    *key_out = bk;
-    return best;
-}
-
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_dd_pos(SimState S, int par) {
+// Body-body manifolds (and grab joints) of one world, 8 lanes per world.  The oracle solves them
+// one after the other in (i<j) pair order; manifolds that share no body commute exactly, so lane q
+// takes the q-th accepted manifold of the sorted order and runs as soon as no EARLIER manifold that
+// is still pending touches one of its bodies.  Disjoint pairs are solved in one round instead of
+// one after the other; the result is bit-identical to the sequential order.
+template <bool POS>
+__global__ void __launch_bounds__(64) k_dd(SimState S, int par) {
+    constexpr int GL = 8;
     const int N = S.N;
     const int total = S.counters[par * 4 + 2];
-    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
-        const int w = S.ddwList[it];
-        if (S.wflags[w]) {
+    const int q = threadIdx.x % GL;
+    const int gbit0 = (threadIdx.x & 63) / GL * GL;               // first lane of this group in the wave
+    for (int it = (blockIdx.x * 64 + threadIdx.x) / GL; ; it += gridDim.x * (64 / GL)) {
+        if (__ballot(it < total) == 0ull) break;                  // wave-uniform exit
+        const bool live = it < total;
+        const int w = live ? S.ddwList[it] : 0;
+        if (POS && live && q == 0 && S.wflags[w]) {
             const int teams = S.teams[w];
             for (int a = 0; a < kMaxAgents; ++a) {
                 if (!team_agent_active(teams, a)) continue;
@@ -422,50 +421,67 @@ __global__ void __launch_bounds__(64) k_dd_pos(SimState S, int par) {
                 solve_grab_joint_bodies(A, B, {gd[0], gd[1], gd[2]}, {gd[3], gd[4], gd[5], gd[6]}, gd[7]);
                 gbody_store_pose(S, w, kAgentSlot0 + a, A); gbody_store_pose(S, w, other, B);
             }
+            __threadfence_block();
         }
         ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
-        const int ndd = S.ndd[w] < kMaxDDCand ? S.ndd[w] : kMaxDDCand;
-        int last = -1;
-        for (int c = 0; c < ndd; ++c) {
-            int key;
-            const int k = next_sorted(S.ddPair, N, w, ndd, last, &key);
-            if (k < 0) break;
-            last = key;
-            if (wsDD[k].np <= 0) continue;
-            ManDD m = wsDD[k];                      // whole manifold in one burst of dwordx4 loads
-            BodyS Ab, Bb;
-            gbody_load(S, w, m.a, Ab); gbody_load(S, w, m.b, Bb);
-            const V3 n = ld3(m.n);
+        int ndd = 0;
+        if (live) ndd = S.ndd[w] < kMaxDDCand ? S.ndd[w] : kMaxDDCand;
+        // keys of the accepted candidates, kMaxDDCand = 16: lane q inspects candidates q and q+8
+        int key0 = 0x7fffffff, key1 = 0x7fffffff;
+        if (q < ndd && wsDD[q].np > 0) { const int p = S.ddPair[q * N + w]; key0 = ((p & 0xff) << 8) | (p >> 8); }
+        if (q + GL < ndd && wsDD[q + GL].np > 0) { const int p = S.ddPair[(q + GL) * N + w]; key1 = ((p & 0xff) << 8) | (p >> 8); }
+        // rank of every accepted candidate in sorted key order (keys are unique: distinct pairs)
+        int rank0 = 0, rank1 = 0, nacc = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < m.np) wsDD[k].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
-            gbody_store_pose(S, w, m.a, Ab); gbody_store_pose(S, w, m.b, Bb);
+        for (int p = 0; p < GL; ++p) {
+            const int k0 = __shfl(key0, gbit0 + p), k1 = __shfl(key1, gbit0 + p);
+            rank0 += (k0 < key0) + (k1 < key0); rank1 += (k0 < key1) + (k1 < key1);
+            nacc += (k0 != 0x7fffffff) + (k1 != 0x7fffffff);
         }
-    }
-}
-
-__global__ void __launch_bounds__(64) k_dd_vel(SimState S, int par) {
-    const int N = S.N;
-    const int total = S.counters[par * 4 + 2];
-    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
-        const int w = S.ddwList[it];
-        ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
-        const int ndd = S.ndd[w] < kMaxDDCand ? S.ndd[w] : kMaxDDCand;
-        int last = -1;
-        for (int c = 0; c < ndd; ++c) {
-            int key;
-            const int k = next_sorted(S.ddPair, N, w, ndd, last, &key);
-            if (k < 0) break;
-            last = key;
-            if (wsDD[k].np <= 0) continue;
-            const ManDD m = wsDD[k];
-            BodyS Ab, Bb;
-            gbody_load(S, w, m.a, Ab); gbody_load(S, w, m.b, Bb);
-            const V3 n = ld3(m.n);
+        for (int base = 0; base < kMaxDDCand; base += GL) {
+            if (__ballot(base < nacc) == 0ull) break;
+            // lane q takes the manifold of rank base+q: find which lane/slot holds it
+            int mine = -1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
-            gbody_store_vel(S, w, m.a, Ab); gbody_store_vel(S, w, m.b, Bb);
+            for (int p = 0; p < GL; ++p) {
+                const int r0 = __shfl(rank0, gbit0 + p), r1 = __shfl(rank1, gbit0 + p);
+                const int k0 = __shfl(key0, gbit0 + p), k1 = __shfl(key1, gbit0 + p);
+                if (k0 != 0x7fffffff && r0 == base + q) mine = p;
+                if (k1 != 0x7fffffff && r1 == base + q) mine = p + GL;
+            }
+            int ma = -1, mb = -1;
+            if (mine >= 0) { ma = wsDD[mine].a; mb = wsDD[mine].b; }
+            bool pending = mine >= 0;
+            while (true) {
+                const unsigned long long pend_mask = __ballot(pending);
+                if (pend_mask == 0ull) break;
+                bool ready = pending;
+#pragma unroll
+                for (int p = 0; p < GL; ++p) {
+                    const int pa = __shfl(ma, gbit0 + p), pb = __shfl(mb, gbit0 + p);
+                    const bool ppend = (pend_mask >> (gbit0 + p)) & 1ull;
+                    if (p < q && ppend && (pa == ma || pa == mb || pb == ma || pb == mb)) ready = false;
+                }
+                if (ready) {
+                    ManDD m = wsDD[mine];
+                    BodyS Ab, Bb;
+                    gbody_load(S, w, m.a, Ab); gbody_load(S, w, m.b, Bb);
+                    const V3 n = ld3(m.n);
+                    if (POS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < m.np) wsDD[mine].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+                        gbody_store_pose(S, w, m.a, Ab); gbody_store_pose(S, w, m.b, Bb);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
+                        gbody_store_vel(S, w, m.a, Ab); gbody_store_vel(S, w, m.b, Bb);
+                    }
+                    pending = false;
+                }
+                __threadfence_block();        // later rounds of this wave must see the poses just written
+            }
         }
     }
 }
