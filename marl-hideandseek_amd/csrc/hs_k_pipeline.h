@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) 
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int N = S.N;
     if (t == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }   // next substep's lists
-    if (t >= NS * N) return;
-    const int slot = t / N, w = t - slot * N;
+    if (t >= NS * S.wcnt) return;
+    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
     if (slot == 0) {
         S.ndd[w] = 0; S.nsc[w] = 0;
         bool grab = false;
@@ -145,9 +145,9 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
     __shared__ int wtot[3][NW];
     __shared__ int bbase[3];
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
-    const int w = blockIdx.x * WPB + grp;
+    const int w = S.wbeg + blockIdx.x * WPB + grp;
     const int N = S.N;
-    const bool wok = w < N;
+    const bool wok = w < S.wbeg + S.wcnt;
     DetectWorld &dw = sh[grp];
     int *cnt = S.counters + par * 4;
     int nwl = 0, npl = 0;
@@ -490,8 +490,8 @@ __global__ void __launch_bounds__(64) k_dd(SimState S, int par) {
 __global__ void __launch_bounds__(256) k_ground_pos(SimState S, int NS) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int N = S.N;
-    if (t >= NS * N) return;
-    const int slot = t / N, w = t - slot * N;
+    if (t >= NS * S.wcnt) return;
+    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
     const int gword = S.gman[slot * N + w];
@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(256) k_ground_pos(SimState S, int NS) {
 __global__ void __launch_bounds__(256) k_ground_vel(SimState S, int NS) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int N = S.N;
-    if (t >= NS * N) return;
-    const int slot = t / N, w = t - slot * N;
+    if (t >= NS * S.wcnt) return;
+    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
     const int gword = S.gman[slot * N + w];
@@ -617,9 +617,9 @@ __global__ void __launch_bounds__(256) k_pre(SimState S) {
     constexpr int G = 16, WPB = 256 / G;
     __shared__ ActWorld sh[WPB];
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
-    const int w = blockIdx.x * WPB + grp;
+    const int w = S.wbeg + blockIdx.x * WPB + grp;
     const int N = S.N, A_ = S.A;
-    const bool wok = w < N;
+    const bool wok = w < S.wbeg + S.wcnt;
     ActWorld &pw = sh[grp];
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     int teams = 0, step = 0;
@@ -693,9 +693,9 @@ __global__ void __launch_bounds__(256) k_post(SimState S) {
     __shared__ WorldGeom sh[WPB];
     __shared__ int seen_flag[WPB];
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
-    const int w = blockIdx.x * WPB + grp;
+    const int w = S.wbeg + blockIdx.x * WPB + grp;
     const int N = S.N, A_ = S.A;
-    const bool wok = w < N;
+    const bool wok = w < S.wbeg + S.wcnt;
     WorldGeom &g = sh[grp];
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     int teams = 0, step = 0, counts = 0;

@@ -20,6 +20,7 @@ struct SimState {
     RandKey initKey;       // rand::initKey(seed) (src/mgr.cpp:678)
     int minHiders, maxHiders, minSeekers, maxSeekers;
     int worldOffset;
+    int wbeg, wcnt;        // world range processed by a launch of the physics pipeline (a chunk of [0, N))
 
     // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
     float *bpos;           // [3][17][N]
