@@ -366,21 +366,24 @@ HSD bool collide_hulls(const HullRef &A, const HullRef &B, const ClipBuf &cb, Ra
         m.n = axE; m.np = 1; m.pA[0] = c1; m.pB[0] = c2;
         return true;
     }
+    // face contact: pick the reference hull first so that the (long) clipping code runs once per wave
+    // whichever body owns the reference face
     V3 pinc[4]; float dist[4];
-    if (bestB > 0.98f * bestA + 0.00125f) {
-        V3 nr = hull_fn(B, fb);
-        int c = clip_face_contact(B, fb, nr, A, cb, pinc, dist);
-        if (c == 0) return false;
-        m.n = -nr; m.np = c;
+    const bool refB = bestB > 0.98f * bestA + 0.00125f;
+    HullRef R, I;
+    R.kind = refB ? B.kind : A.kind; I.kind = refB ? A.kind : B.kind;
+    R.c = vsel(refB, B.c, A.c); R.ax = vsel(refB, B.ax, A.ax); R.ay = vsel(refB, B.ay, A.ay); R.az = vsel(refB, B.az, A.az); R.e = vsel(refB, B.e, A.e);
+    I.c = vsel(refB, A.c, B.c); I.ax = vsel(refB, A.ax, B.ax); I.ay = vsel(refB, A.ay, B.ay); I.az = vsel(refB, A.az, B.az); I.e = vsel(refB, A.e, B.e);
+    const int fr = refB ? fb : fa;
+    const V3 nr = hull_fn(R, fr);
+    const int c = clip_face_contact(R, fr, nr, I, cb, pinc, dist);
+    if (c == 0) return false;
+    m.n = refB ? -nr : nr; m.np = c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (i < c) { m.pA[i] = pinc[i]; m.pB[i] = pinc[i] - nr * dist[i]; }
-    } else {
-        V3 nr = hull_fn(A, fa);
-        int c = clip_face_contact(A, fa, nr, B, cb, pinc, dist);
-        if (c == 0) return false;
-        m.n = nr; m.np = c;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (i < c) { m.pB[i] = pinc[i]; m.pA[i] = pinc[i] - nr * dist[i]; }
+    for (int i = 0; i < 4; ++i) if (i < c) {
+        const V3 on_ref = pinc[i] - nr * dist[i];
+        m.pA[i] = refB ? pinc[i] : on_ref;
+        m.pB[i] = refB ? on_ref : pinc[i];
     }
     return true;
 }
