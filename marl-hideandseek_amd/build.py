@@ -38,5 +38,17 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_headless():
+    """C++ headless driver over the C ABI (reference: src/headless.cpp)."""
+    out = os.path.join(HERE, "lib", "headless")
+    src = os.path.join(HERE, "tools", "headless.cpp")
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(os.path.dirname(HERE), "include"), src,
+                           "-L", os.path.join(HERE, "lib"), "-lhideseek", "-Wl,-rpath,$ORIGIN", "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_headless())
