@@ -141,6 +141,9 @@ int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */
 int32_t hs_debug_calibrate(int64_t bytes);
 
+/* No-op `DLManagedTensor::deleter` for the non-owning DLPack views built by language bindings. */
+void hs_dlpack_noop_deleter(void *managed_tensor);
+
 const char *hs_last_error(void);
 const char *hs_version(void);
 

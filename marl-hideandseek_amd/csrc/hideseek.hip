@@ -421,6 +421,11 @@ int32_t hs_debug_calibrate(int64_t bytes) {
     return HS_OK;
 }
 
+// DLPack deleter for the non-owning tensor views handed to Python: the simulator owns the memory, the
+// binding keeps the DLManagedTensor records alive, so there is nothing to free (and nothing here may call
+// back into an interpreter that is shutting down).
+void hs_dlpack_noop_deleter(void *) {}
+
 int32_t hs_set_profiling(hs_sim *s, int32_t enabled) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     s->profiling = enabled != 0;

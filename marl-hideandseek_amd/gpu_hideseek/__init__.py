@@ -8,9 +8,11 @@ the simulator's HBM buffers exported through DLPack (``Tensor.to_torch`` / ``Ten
 
 There is no CPU execution path: if the HIP library or a GPU is missing the constructor raises.
 """
+import atexit
 import ctypes as C
 import enum
 import os
+import weakref
 
 __all__ = ["HideAndSeekSimulator", "SimFlags", "madrona", "Tensor", "library_path"]
 
@@ -77,12 +79,10 @@ _DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_
 _kDLROCM = 10
 _DTYPES = {0: (0, 32, "int32"), 1: (2, 32, "float32"), 2: (1, 8, "uint8")}   # id -> (code, bits, name)
 
-_live_exports = {}    # id(managed) -> python objects that back a live DLPack capsule
-
-
-@_DLDeleter
-def _dl_deleter(mt_ptr):
-    _live_exports.pop(C.addressof(mt_ptr.contents), None)
+# DLManagedTensor records handed out so far.  They are tiny, non-owning and must outlive every consumer
+# (torch may run the deleter while the interpreter is shutting down, so the deleter is a C no-op in
+# libhideseek and the records are simply kept for the life of the process).
+_live_exports = []
 
 
 class Tensor:
@@ -115,8 +115,8 @@ class Tensor:
         mt.dl_tensor.strides = None
         mt.dl_tensor.byte_offset = 0
         mt.manager_ctx = None
-        mt.deleter = _dl_deleter
-        _live_exports[C.addressof(mt)] = (mt, shape, self._owner)
+        mt.deleter = C.cast(_load().hs_dlpack_noop_deleter, _DLDeleter)
+        _live_exports.append((mt, shape))
         new_capsule = C.pythonapi.PyCapsule_New
         new_capsule.restype = C.py_object
         new_capsule.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -195,6 +195,16 @@ _EXPORTS = dict(reset=0, prep_counter=1, action=2, self_data=3, self_type=4, sel
                 episode_result=18, ckpt_ctrl=19, ckpt=20, depth=21, rgb=22)
 
 
+_live_sims = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # destroy simulators while the HIP runtime is still loaded (its own teardown runs after Py_Finalize)
+    for s in list(_live_sims):
+        s.close()
+
+
 class HideAndSeekSimulator:
     """gpu_hideseek.HideAndSeekSimulator (src/bindings.cpp:31-118)."""
 
@@ -211,12 +221,17 @@ class HideAndSeekSimulator:
         self._L = L
         self.num_worlds = int(num_worlds)
         self.agents_per_world = L.hs_agents_per_world(self._h)
+        _live_sims.add(self)
 
-    def __del__(self):
+    def close(self):
+        """Manager::~Manager (mgr.cpp:848-859).  Tensor views must not be used afterwards."""
         h = getattr(self, "_h", None)
         if h:
             self._L.hs_destroy(h)
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     def init(self):
         _check(self._L.hs_init(self._h))
