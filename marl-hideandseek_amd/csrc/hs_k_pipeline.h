@@ -237,14 +237,17 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
             S.satList[gbase++] = (w << 6) | (bdd[jb] + i);
             ++i;
         }
-        unsigned long long sm = s_mask[jb]; i = 0;
+        // oracle order inside a body: extra planes first, then walls by index; the body's candidates
+        // occupy the contiguous range [bsc, bsc + asc) of the world's list
+        unsigned long long sm = (s_mask[jb] >> kMaxWalls) | (s_mask[jb] << (64 - kMaxWalls) >> (64 - kMaxWalls) << kMaxPlanes); i = 0;
         while (sm && i < asc[jb]) {
-            const int k = __ffsll((long long)sm) - 1; sm &= sm - 1;
+            const int bit = __ffsll((long long)sm) - 1; sm &= sm - 1;
+            const int k = bit < kMaxPlanes ? kMaxWalls + bit : bit - kMaxPlanes;
             S.scPair[(bsc[jb] + i) * N + w] = slot | (k << 8);
             S.satList[gbase++] = (w << 6) | 32 | (bsc[jb] + i);
             ++i;
         }
-        if (asc[jb] > 0) S.wallList[wbase2++] = (w << 5) | slot;
+        if (asc[jb] > 0) S.wallList[wbase2++] = (int)(((unsigned)w << 15) | (bsc[jb] << 10) | (asc[jb] << 5) | slot);
     }
     if (push_ddw) S.ddwList[bbase[2] + wtot[2][wv] + incl[2] - 1] = w;
     __syncthreads();
@@ -537,39 +540,17 @@ __global__ void __launch_bounds__(256) k_ground_vel(SimState S, int NS) {
     gbody_store_vel(S, w, slot, me);
 }
 
-// next static candidate of `slot` in increasing static-id order after `last`; -1 when done
-HSD int next_static(const int *pairs, int N, int w, int n, int slot, int last_st, int *st_out) {
-    int best = -1, bs = 0x7fffffff;
-    for (int k = 0; k < n; ++k) {
-        const int p = pairs[k * N + w];
-        if ((p & 0xff) != slot) continue;
-        const int st = p >> 8;
-        // oracle order: planes 1.. first, then walls by index
-        const int key = st >= kMaxWalls ? st - kMaxWalls : st + kMaxPlanes;
-        if (key > last_st && key < bs) { bs = key; best = k; }
-    }
-    *st_out = bs;
-    return best;
-}
-
 __global__ void __launch_bounds__(64) k_walls_pos(SimState S, int par) {
-    const int N = S.N;
     const int total = S.counters[par * 4 + 1];
     for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
-        const int item = S.wallList[it];
-        const int w = item >> 5, slot = item & 31;
+        const unsigned item = (unsigned)S.wallList[it];
+        const int w = item >> 15, bsc = (item >> 10) & 31, asc = (item >> 5) & 31, slot = item & 31;
         ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
-        const int nsc = S.nsc[w] < kMaxSCand ? S.nsc[w] : kMaxSCand;
         BodyS me, none;
         gbody_load(S, w, slot, me);
-        int last = -1;
-        for (int c = 0; c < nsc; ++c) {
-            int key;
-            const int k = next_static(S.scPair, N, w, nsc, slot, last, &key);
-            if (k < 0) break;
-            last = key;
-            if (wsSC[k].np <= 0) continue;
+        for (int k = bsc; k < bsc + asc; ++k) {       // the body's candidates, already in solve order
             ManS m = wsSC[k];
+            if (m.np <= 0) continue;
             body_refresh_inertia(me);
             const V3 n = ld3(m.n);
 #pragma unroll
@@ -582,23 +563,16 @@ __global__ void __launch_bounds__(64) k_walls_pos(SimState S, int par) {
 }
 
 __global__ void __launch_bounds__(64) k_walls_vel(SimState S, int par) {
-    const int N = S.N;
     const int total = S.counters[par * 4 + 1];
     for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
-        const int item = S.wallList[it];
-        const int w = item >> 5, slot = item & 31;
+        const unsigned item = (unsigned)S.wallList[it];
+        const int w = item >> 15, bsc = (item >> 10) & 31, asc = (item >> 5) & 31, slot = item & 31;
         const ManS *const wsSC = (const ManS *)S.wsSC + (size_t)w * kMaxSCand;
-        const int nsc = S.nsc[w] < kMaxSCand ? S.nsc[w] : kMaxSCand;
         BodyS me, none;
         gbody_load(S, w, slot, me);
-        int last = -1;
-        for (int c = 0; c < nsc; ++c) {
-            int key;
-            const int k = next_static(S.scPair, N, w, nsc, slot, last, &key);
-            if (k < 0) break;
-            last = key;
-            if (wsSC[k].np <= 0) continue;
+        for (int k = bsc; k < bsc + asc; ++k) {
             const ManS m = wsSC[k];
+            if (m.np <= 0) continue;
             body_refresh_inertia(me);
             const V3 n = ld3(m.n);
 #pragma unroll
