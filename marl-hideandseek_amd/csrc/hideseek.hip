@@ -109,7 +109,14 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     if (stages & 2) hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
     if ((stages & 4) && !(S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS))
-        hipLaunchKernelGGL(hs::k_observe, dim3(N), dim3(256), 0, strm, S);
+    {
+        const int nt = (s->A * hs::kRaysPerAgent + 63) / 64 * 64;      // one lane per ray, whole waves
+        if (nt <= 64) hipLaunchKernelGGL(hs::k_observe<64>, dim3(N), dim3(64), 0, strm, S);
+        else if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);
+        else if (nt <= 192) hipLaunchKernelGGL(hs::k_observe<192>, dim3(N), dim3(192), 0, strm, S);
+        else if (nt <= 256) hipLaunchKernelGGL(hs::k_observe<256>, dim3(N), dim3(256), 0, strm, S);
+        else hipLaunchKernelGGL(hs::k_observe<320>, dim3(N), dim3(320), 0, strm, S);
+    }
     if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
     HS_HIP(hipGetLastError());
     return HS_OK;

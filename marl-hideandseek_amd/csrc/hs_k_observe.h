@@ -70,12 +70,15 @@ HSD void stage_world(const SimState &S, int w, ObsShared &sh, int tid) {
 HSD unsigned long long ray_key(float t, int id) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id; }
 constexpr unsigned kKeyMiss = 0xffffffffu;
 
-__global__ void __launch_bounds__(256) k_observe(SimState S) {
+// NT = threads per world = A*46 rays rounded up to whole waves (192 for the 4-agent benchmark): every
+// lane of pass 1 / pass 3 has a ray.
+template <int NT>
+__global__ void __launch_bounds__(NT) k_observe(SimState S) {
     __shared__ ObsShared sh;
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     const int A = S.A;
-    stage_world<256>(S, w, sh, tid);
+    stage_world<NT>(S, w, sh, tid);
     const int counts = S.counts[w];
     const int teams = S.teams[w];
     const int step = S.curEpisodeStep[w];
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) k_observe(SimState S) {
     const int nRays = A * kRaysPerAgent;
 
     // ---------------- pass 1: ray setup, walls + planes, cull against the movable hulls ----------------
-    for (int r = tid; r < nRays; r += 256) {
+    for (int r = tid; r < nRays; r += NT) {
         const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
         sh.rayKey[r] = ray_key(-1.f, kKeyMiss);               // "no ray" (visibility ray not cast)
         if (i >= nAgents) continue;
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) k_observe(SimState S) {
     // ---------------- pass 2: exact ray-vs-hull tests, one thread per surviving pair ----------------
     {
         const int np2 = sh.nPairs < kMaxPairs ? sh.nPairs : kMaxPairs;
-        for (int p = tid; p < np2; p += 256) {
+        for (int p = tid; p < np2; p += NT) {
             const int pr = sh.pairs[p];
             const int r = pr >> 5, b = pr & 31;
             const int obj = meta_obj(g.meta[b]);
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(256) k_observe(SimState S) {
     }
     __syncthreads();
     // ---------------- pass 3: ray results -> exported columns ----------------
-    for (int r = tid; r < nRays; r += 256) {
+    for (int r = tid; r < nRays; r += NT) {
         const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
         if (i >= nAgents) continue;
         const int row = w * A + i;
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(256) k_observe(SimState S) {
     }
     // ---------------- collectObservationsSystem rows + globalPositionsDebugSystem ----------------
     const int nObs = A * 17;
-    for (int item = tid; item < nObs + 1; item += 256) {
+    for (int item = tid; item < nObs + 1; item += NT) {
         if (item < nObs) {
             const int i = item / 17, e = item % 17;
             if (i >= nAgents) continue;
