@@ -101,6 +101,31 @@ typedef struct hs_tensor_desc {
     int32_t gpu_id;
 } hs_tensor_desc;
 
+/* Checkpoint (src/sim.hpp:283-313): the per-world snapshot behind `ckpt_tensor()` ([N, 1392] u8) and the
+ * replay log of scripts/jax_infer.py:125.  Field order follows the reference struct; Quat is w,x,y,z,
+ * Velocity is linear then angular.  The engine's JointConstraint::Fixed is not in the reference tree:
+ * {attachRot1, attachRot2, separation} is assumed, which reproduces the 1392-byte record. */
+typedef struct hs_ckpt_object {          /* Checkpoint::DynObjectState (sim.hpp:294-297) */
+    float pos[3], rot[4], lin[3], ang[3];
+    uint32_t team;                        /* OwnerTeam: 0 None, 1 Seeker, 2 Hider, 3 Unownable (sim.hpp:127-132) */
+    uint8_t is_locked, _pad[3];
+} hs_ckpt_object;
+typedef struct hs_ckpt_agent {           /* Checkpoint::AgentState (sim.hpp:299-304) */
+    float pos[3], rot[4], lin[3], ang[3];
+    int32_t grab_idx;                     /* box index, or numBoxes + ramp index, or -1 */
+    float grab_r1[3], grab_r2[3];
+    float attach_rot1[4], attach_rot2[4], separation;
+} hs_ckpt_agent;
+typedef struct hs_checkpoint {
+    uint32_t episode_key[2];              /* curEpisodeRNDCounter = {episode index, world id} */
+    int32_t running_scores[2];            /* EpisodeStats (sim.hpp:109-111) */
+    int32_t episode_step;
+    hs_ckpt_agent agents[6];              /* hiders, then seekers */
+    hs_ckpt_object boxes[9];
+    hs_ckpt_object ramps[2];
+    int32_t num_hiders, num_seekers, num_boxes, num_ramps;
+} hs_checkpoint;
+
 /* Manager::Manager (src/mgr.cpp:844-846 -> Impl::make :674-822). */
 int32_t hs_create(const hs_config *cfg, hs_sim **out);
 /* Manager::~Manager (src/mgr.cpp:848-859). */
@@ -119,6 +144,34 @@ int32_t hs_get_tensor(hs_sim *sim, int32_t export_id, hs_tensor_desc *out);
 int32_t hs_trigger_reset(hs_sim *sim, int32_t world_idx, int32_t level_idx);
 /* Manager::setAction (src/mgr.cpp:1283-1305). */
 int32_t hs_set_action(hs_sim *sim, int32_t agent_idx, int32_t x, int32_t y, int32_t r, int32_t g, int32_t l);
+/* Manager::saveCheckpoint (src/mgr.cpp:905-929): set world's CheckpointControl trigger, run the
+ * SaveCheckpoints graph (sim.cpp:1315-1322: every triggered world writes its hs_checkpoint and clears the
+ * trigger); blocking. */
+int32_t hs_save_checkpoint(hs_sim *sim, int32_t world_idx);
+/* Manager::loadCheckpoint (src/mgr.cpp:931-963): set the trigger, run the LoadCheckpoints graph. */
+int32_t hs_load_checkpoint(hs_sim *sim, int32_t world_idx);
+/* Manager::loadCheckpoints (src/mgr.cpp:965-985): run the LoadCheckpoints graph (sim.cpp:1324-1333) for
+ * the triggers currently in the ckpt_ctrl tensor: triggered worlds regenerate their level from the saved
+ * episode key and restore body / joint / episode state (sim.cpp:956-1044, trigger left at 1 as :963 does);
+ * then observations are recomputed for all worlds. */
+int32_t hs_load_checkpoints(hs_sim *sim);
+/* CUDAImpl::saveCheckpoints (src/mgr.cpp:316-319): run the SaveCheckpoints graph for the current triggers. */
+int32_t hs_save_checkpoints(hs_sim *sim);
+
+/* The XLA-callable entry points behind `sim.jax()` (src/bindings.cpp:97-118): enqueue on the caller's
+ * hipStream_t, device buffers in the reference's order, no synchronisation except hs_jax_init.
+ *   obs block (JAXIOObservations, mgr.cpp:168-201): prep_counter, self_data, self_type, self_mask, lidar,
+ *   agent_data, box_data, ramp_data, vis_agents_mask, vis_boxes_mask, vis_ramps_mask.
+ * hs_jax_init  (gpuStreamInit mgr.cpp:362-376):  buffers = obs block (out).
+ * hs_jax_step  (gpuStreamStep mgr.cpp:379-398):  buffers = actions, resets, policy_assignments (in), obs block,
+ *                                                rewards, dones, episode_results (out).
+ * hs_jax_save_checkpoints (mgr.cpp:400-416):     buffers = ckpt_ctrl (in), ckpts (out).
+ * hs_jax_load_checkpoints (mgr.cpp:418-436):     buffers = ckpt_ctrl, ckpts (in), obs block (out). */
+int32_t hs_jax_init(hs_sim *sim, void *hip_stream, void **buffers);
+int32_t hs_jax_step(hs_sim *sim, void *hip_stream, void **buffers);
+int32_t hs_jax_save_checkpoints(hs_sim *sim, void *hip_stream, void **buffers);
+int32_t hs_jax_load_checkpoints(hs_sim *sim, void *hip_stream, void **buffers);
+
 /* maxAgentsPerWorld (src/mgr.cpp:684). */
 int32_t hs_agents_per_world(const hs_sim *sim);
 

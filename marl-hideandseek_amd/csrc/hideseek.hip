@@ -67,6 +67,18 @@ void set_desc(hs_sim *s, int id, void *ptr, int dtype, std::initializer_list<int
     for (; i < 4; ++i) d.dims[i] = 1;
 }
 
+void launch_observe(hs_sim *s, hipStream_t strm) {
+    const hs::SimState &S = s->S;
+    if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
+    const int N = S.N;
+    const int nt = (s->A * hs::kRaysPerAgent + 63) / 64 * 64;      // one lane per ray, whole waves
+    if (nt <= 64) hipLaunchKernelGGL(hs::k_observe<64>, dim3(N), dim3(64), 0, strm, S);
+    else if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);
+    else if (nt <= 192) hipLaunchKernelGGL(hs::k_observe<192>, dim3(N), dim3(192), 0, strm, S);
+    else if (nt <= 256) hipLaunchKernelGGL(hs::k_observe<256>, dim3(N), dim3(256), 0, strm, S);
+    else hipLaunchKernelGGL(hs::k_observe<320>, dim3(N), dim3(320), 0, strm, S);
+}
+
 int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7) {
     const hs::SimState &S = s->S;
     const int N = S.N;
@@ -108,15 +120,7 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     if (stages & 2) hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
-    if ((stages & 4) && !(S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS))
-    {
-        const int nt = (s->A * hs::kRaysPerAgent + 63) / 64 * 64;      // one lane per ray, whole waves
-        if (nt <= 64) hipLaunchKernelGGL(hs::k_observe<64>, dim3(N), dim3(64), 0, strm, S);
-        else if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);
-        else if (nt <= 192) hipLaunchKernelGGL(hs::k_observe<192>, dim3(N), dim3(192), 0, strm, S);
-        else if (nt <= 256) hipLaunchKernelGGL(hs::k_observe<256>, dim3(N), dim3(256), 0, strm, S);
-        else hipLaunchKernelGGL(hs::k_observe<320>, dim3(N), dim3(320), 0, strm, S);
-    }
+    if (stages & 4) launch_observe(s, strm);
     if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
     HS_HIP(hipGetLastError());
     return HS_OK;
@@ -199,7 +203,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.numWalls, N); HS_ALLOC(S.numPlanes, N);
     HS_ALLOC(S.curWorldEpisode, N); HS_ALLOC(S.rngKeyA, N); HS_ALLOC(S.rngKeyB, N); HS_ALLOC(S.rngCount, N);
     HS_ALLOC(S.curEpisodeStep, N); HS_ALLOC(S.hiderTeamReward, N); HS_ALLOC(S.counts, N); HS_ALLOC(S.teams, N);
-    HS_ALLOC(S.runningScores, 2 * N); HS_ALLOC(S.grabOther, AG * N); HS_ALLOC(S.grabData, 8 * AG * N);
+    HS_ALLOC(S.runningScores, 2 * N); HS_ALLOC(S.grabOther, AG * N); HS_ALLOC(S.grabData, hs::kGrabWords * AG * N);
+    HS_ALLOC(S.epKeyA, N); HS_ALLOC(S.epKeyB, N); HS_ALLOC(S.xCkptCtrl, N); HS_ALLOC(S.xCkpt, N * sizeof(hs_checkpoint));
     HS_ALLOC(S.xReset, N); HS_ALLOC(S.xPrep, R); HS_ALLOC(S.xAction, R * 5); HS_ALLOC(S.xSelfType, R);
     HS_ALLOC(S.xSeed, R * 2); HS_ALLOC(S.xDone, R); HS_ALLOC(S.xPolicy, R);
     HS_ALLOC(S.xSelfObs, R * 13); HS_ALLOC(S.xSelfMask, R); HS_ALLOC(S.xAgentObs, R * 5 * 14);
@@ -272,6 +277,9 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     set_desc(s, HS_EXPORT_GLOBAL_DEBUG_POSITIONS, S.xGlobalPos, HS_DTYPE_F32, {n, 17, 2});
     set_desc(s, HS_EXPORT_AGENT_POLICY, S.xPolicy, HS_DTYPE_I32, {r, 1});
     set_desc(s, HS_EXPORT_EPISODE_RESULT, S.xEpisodeResult, HS_DTYPE_F32, {n, 2});
+    // raw bytes, as the reference exports them (mgr.cpp:1209-1227)
+    set_desc(s, HS_EXPORT_CHECKPOINT_CONTROL, S.xCkptCtrl, HS_DTYPE_U8, {n, (int64_t)sizeof(int32_t)});
+    set_desc(s, HS_EXPORT_CHECKPOINT, S.xCkpt, HS_DTYPE_U8, {n, (int64_t)sizeof(hs_checkpoint)});
     *out = s;
     return HS_OK;
 }
@@ -321,7 +329,7 @@ int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     if (id < 0 || id >= HS_NUM_EXPORTS) return fail(HS_ERR_INVALID_ARG, "export id out of range");
     if (!s->exports[id].ptr) {
-        // renderer / checkpoint outputs are allocated on first request and never written
+        // renderer outputs are allocated on first request and never written
         HS_HIP(hipSetDevice(s->cfg.gpu_id));
         const int64_t n = s->S.N, r = (int64_t)s->S.N * s->A;
         const int64_t H = s->cfg.batch_render_height > 0 ? s->cfg.batch_render_height : 64;
@@ -333,12 +341,6 @@ int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
         } else if (id == HS_EXPORT_DEPTH) {
             float *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd))) != HS_OK) return rc;
             set_desc(s, id, p, HS_DTYPE_F32, {r, H, Wd, 1});
-        } else if (id == HS_EXPORT_CHECKPOINT_CONTROL) {
-            int32_t *p; if ((rc = s->dalloc(&p, (size_t)n)) != HS_OK) return rc;
-            set_desc(s, id, p, HS_DTYPE_I32, {n, 1});
-        } else if (id == HS_EXPORT_CHECKPOINT) {
-            uint8_t *p; if ((rc = s->dalloc(&p, (size_t)(n * 1392))) != HS_OK) return rc;
-            set_desc(s, id, p, HS_DTYPE_U8, {n, 1392});
         } else {
             return fail(HS_ERR_INVALID_ARG, "export not available");
         }
@@ -360,6 +362,129 @@ int32_t hs_set_action(hs_sim *s, int32_t agent, int32_t x, int32_t y, int32_t r,
     int32_t a[5] = {x, y, r, g ? 1 : 0, l ? 1 : 0};
     HS_HIP(hipMemcpy(s->S.xAction + (size_t)agent * 5, a, sizeof(a), hipMemcpyHostToDevice));
     return HS_OK;
+}
+
+// ---- checkpoints (sim.cpp:956-1137, 1315-1333) ----
+namespace {
+int launch_save_ckpts(hs_sim *s, hipStream_t strm) {
+    hipLaunchKernelGGL(hs::k_save_ckpt, dim3((s->S.N + 63) / 64), dim3(64), 0, strm, s->S);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+int launch_load_ckpts(hs_sim *s, hipStream_t strm) {
+    hipLaunchKernelGGL(hs::k_load_ckpt, dim3((s->S.N + 63) / 64), dim3(64), 0, strm, s->S);
+    launch_observe(s, strm);              // postGenTasks + observationsTasks for every world (sim.cpp:1331-1332)
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+int set_ckpt_trigger(hs_sim *s, int32_t world) {
+    if (world < 0 || world >= s->S.N) return fail(HS_ERR_INVALID_ARG, "world index out of range");
+    const int32_t one = 1;
+    HS_HIP(hipMemcpy(s->S.xCkptCtrl + world, &one, sizeof(one), hipMemcpyHostToDevice));
+    return HS_OK;
+}
+}  // namespace
+
+int32_t hs_save_checkpoints(hs_sim *s) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = launch_save_ckpts(s, nullptr);
+    if (rc != HS_OK) return rc;
+    HS_HIP(hipStreamSynchronize(nullptr));
+    return HS_OK;
+}
+int32_t hs_load_checkpoints(hs_sim *s) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = launch_load_ckpts(s, nullptr);
+    if (rc != HS_OK) return rc;
+    HS_HIP(hipStreamSynchronize(nullptr));
+    return HS_OK;
+}
+int32_t hs_save_checkpoint(hs_sim *s, int32_t world) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = set_ckpt_trigger(s, world);
+    return rc != HS_OK ? rc : hs_save_checkpoints(s);
+}
+int32_t hs_load_checkpoint(hs_sim *s, int32_t world) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = set_ckpt_trigger(s, world);
+    return rc != HS_OK ? rc : hs_load_checkpoints(s);
+}
+
+// ---- stream entry points with the reference's JAX buffer order (mgr.cpp:168-201, 362-436) ----
+namespace {
+int copy_dd(void *dst, const void *src, size_t bytes, hipStream_t strm) {
+    if (!dst || !src) return fail(HS_ERR_INVALID_ARG, "null device buffer");
+    if (dst == src) return HS_OK;                // the caller passed the simulator's own tensor
+    HS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, strm));
+    return HS_OK;
+}
+// copyOutObservations (mgr.cpp:340-360); returns the advanced buffer cursor through *pp
+int copy_out_observations(hs_sim *s, hipStream_t strm, void ***pp) {
+    const hs::SimState &S = s->S;
+    const size_t R = (size_t)S.N * s->A;
+    const struct { const void *src; size_t bytes; } obs[11] = {
+        {S.xPrep, R * 4}, {S.xSelfObs, R * 13 * 4}, {S.xSelfType, R * 4}, {S.xSelfMask, R * 4}, {S.xLidar, R * 30 * 4},
+        {S.xAgentObs, R * 5 * 14 * 4}, {S.xBoxObs, R * 9 * 17 * 4}, {S.xRampObs, R * 2 * 14 * 4},
+        {S.xVisAgents, R * 5 * 4}, {S.xVisBoxes, R * 9 * 4}, {S.xVisRamps, R * 2 * 4}};
+    for (const auto &o : obs) {
+        int rc = copy_dd(*(*pp)++, o.src, o.bytes, strm);
+        if (rc != HS_OK) return rc;
+    }
+    return HS_OK;
+}
+}  // namespace
+
+int32_t hs_jax_init(hs_sim *s, void *hip_stream, void **buffers) {
+    if (!s || !buffers) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    hipStream_t strm = (hipStream_t)hip_stream;
+    int rc = launch_step(s, strm, true);
+    if (rc == HS_OK) rc = copy_out_observations(s, strm, &buffers);
+    if (rc != HS_OK) return rc;
+    HS_HIP(hipStreamSynchronize(strm));          // gpuStreamInit synchronises (mgr.cpp:376)
+    s->initialised = true;
+    return HS_OK;
+}
+int32_t hs_jax_step(hs_sim *s, void *hip_stream, void **buffers) {
+    if (!s || !buffers) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    hipStream_t strm = (hipStream_t)hip_stream;
+    const hs::SimState &S = s->S;
+    const size_t N = (size_t)S.N, R = N * s->A;
+    int rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
+    if (rc == HS_OK) rc = copy_dd(S.xReset, *buffers++, N * 4, strm);
+    if (rc == HS_OK) rc = copy_dd(S.xPolicy, *buffers++, R * 4, strm);
+    if (rc == HS_OK) rc = launch_step(s, strm, false);
+    if (rc == HS_OK) rc = copy_out_observations(s, strm, &buffers);
+    if (rc == HS_OK) rc = copy_dd(*buffers++, S.xReward, R * 4, strm);
+    if (rc == HS_OK) rc = copy_dd(*buffers++, S.xDone, R * 4, strm);
+    if (rc == HS_OK) rc = copy_dd(*buffers++, S.xEpisodeResult, N * 2 * 4, strm);
+    return rc;
+}
+int32_t hs_jax_save_checkpoints(hs_sim *s, void *hip_stream, void **buffers) {
+    if (!s || !buffers) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    hipStream_t strm = (hipStream_t)hip_stream;
+    const size_t N = (size_t)s->S.N;
+    int rc = copy_dd(s->S.xCkptCtrl, buffers[0], N * 4, strm);
+    if (rc == HS_OK) rc = launch_save_ckpts(s, strm);
+    if (rc == HS_OK) rc = copy_dd(buffers[1], s->S.xCkpt, N * sizeof(hs_checkpoint), strm);
+    return rc;
+}
+int32_t hs_jax_load_checkpoints(hs_sim *s, void *hip_stream, void **buffers) {
+    if (!s || !buffers) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    hipStream_t strm = (hipStream_t)hip_stream;
+    const size_t N = (size_t)s->S.N;
+    int rc = copy_dd(s->S.xCkptCtrl, *buffers++, N * 4, strm);
+    if (rc == HS_OK) rc = copy_dd(s->S.xCkpt, *buffers++, N * sizeof(hs_checkpoint), strm);
+    if (rc == HS_OK) rc = launch_load_ckpts(s, strm);
+    if (rc == HS_OK) rc = copy_out_observations(s, strm, &buffers);
+    return rc;
 }
 
 int32_t hs_debug_dump_bodies(hs_sim *s, float *bodies, int32_t *meta) {

@@ -30,6 +30,7 @@ constexpr float kSubstepH = (1.f / 30.f) / 4.f;
 constexpr float kGravityZ = -9.8f;
 constexpr float kMaxDepenVel = 3.f;
 constexpr int kMaxDDCand = 16;
+constexpr int kGrabWords = 15;      // grab-joint record: r2 3, attach2 4, separation 1, r1 3, attach1 4
 constexpr int kMaxSCand = 24;
 constexpr float kCosFovHalf = 0.382683426f;
 constexpr float kPi = 3.14159265358979323846f;

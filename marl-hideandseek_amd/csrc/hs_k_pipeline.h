@@ -359,9 +359,9 @@ __global__ void __launch_bounds__(64) k_sat(SimState S, int par) {
 }
 
 // Fixed grab joint on two loaded bodies (sim.cpp:343-356): angular alignment, then anchor coincidence.
-HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep) {
+HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep, V3 r1, Q attach1) {
     {
-        Q qa = qmul(A.rot, Q{1.f, 0.f, 0.f, 0.f}), qb = qmul(B.rot, attach2);
+        Q qa = qmul(A.rot, attach1), qb = qmul(B.rot, attach2);
         Q dq = qmul(qa, qinv(qb));
         V3 dphi = {2.f * dq.x, 2.f * dq.y, 2.f * dq.z};
         if (dq.w < 0.f) dphi = -dphi;
@@ -380,7 +380,7 @@ HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep
         }
     }
     {
-        V3 anchorA = V3{0.f, 1.25f, 0.5f} + V3{0.f, sep, 0.f};
+        V3 anchorA = r1 + V3{0.f, sep, 0.f};
         V3 rAw = qrot(A.rot, anchorA), rBw = qrot(B.rot, r2);
         V3 dx = (A.pos + rAw) - (B.pos + rBw);
         float c2 = len2(dx);
@@ -418,10 +418,11 @@ __global__ void __launch_bounds__(64) k_dd(SimState S, int par) {
                 if (other < 0) continue;
                 BodyS A, B;
                 gbody_load(S, w, kAgentSlot0 + a, A); gbody_load(S, w, other, B);
-                float gd[8];
+                float gd[kGrabWords];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) gd[c] = S.grabData[(c * kMaxAgents + a) * N + w];
-                solve_grab_joint_bodies(A, B, {gd[0], gd[1], gd[2]}, {gd[3], gd[4], gd[5], gd[6]}, gd[7]);
+                for (int c = 0; c < kGrabWords; ++c) gd[c] = S.grabData[(c * kMaxAgents + a) * N + w];
+                solve_grab_joint_bodies(A, B, {gd[0], gd[1], gd[2]}, {gd[3], gd[4], gd[5], gd[6]}, gd[7],
+                                        {gd[8], gd[9], gd[10]}, {gd[11], gd[12], gd[13], gd[14]});
                 gbody_store_pose(S, w, kAgentSlot0 + a, A); gbody_store_pose(S, w, other, B);
             }
             __threadfence_block();
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(256) k_pre(SimState S) {
         for (int i = l; i < kMaxAgents; i += G) {
             pw.grabOther[i] = S.grabOther[i * N + w];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) pw.grabData[i][c] = S.grabData[(c * kMaxAgents + i) * N + w];
+            for (int c = 0; c < kGrabWords; ++c) pw.grabData[i][c] = S.grabData[(c * kMaxAgents + i) * N + w];
             if (i >= A_) pw.actGL[i] = 0;
         }
         if (l == 0) { pw.g.numWalls = nw; pw.g.numPlanes = npl; pw.teams = teams; }
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(256) k_pre(SimState S) {
         for (int i = l; i < kMaxAgents; i += G) {
             S.grabOther[i * N + w] = pw.grabOther[i];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) S.grabData[(c * kMaxAgents + i) * N + w] = pw.grabData[i][c];
+            for (int c = 0; c < kGrabWords; ++c) S.grabData[(c * kMaxAgents + i) * N + w] = pw.grabData[i][c];
         }
     }
 }

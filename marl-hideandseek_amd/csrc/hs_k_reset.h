@@ -6,6 +6,7 @@
 // coalesced stores, and its divergence is accepted.  Integer decisions are gated
 // by float compares, so the arithmetic below is order-for-order the oracle's.
 #pragma once
+#include "../../include/hideseek.h"     // hs_checkpoint
 #include "hs_state.h"
 
 namespace hs {
@@ -307,26 +308,33 @@ HSD void gen_debug(GenWorld &g, int level) {                    // level_gen.cpp
     }
 }
 
-__global__ void __launch_bounds__(64) k_reset(SimState S) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+// Regenerate world w: resetSystem's branch (sim.cpp:185-194) when ck == nullptr, loadCheckpointSystem
+// (sim.cpp:956-1044) otherwise — same level generator, but the episode key, agent counts and episode
+// step come from the checkpoint, the world's episode counter is not advanced and the saved body /
+// joint state is written over the generated spawn state.
+template <bool LOAD>
+HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoint *ck) {
     const int N = S.N;
-    if (w >= N) return;
-    int level = S.xReset[w];
-    const int step = S.curEpisodeStep[w];
-    if ((S.flags & FLAG_IGNORE_EPISODE_LENGTH) != FLAG_IGNORE_EPISODE_LENGTH && step == kEpisodeLen - 1) level = 1;
-    if (level == 0) {
-        S.curEpisodeStep[w] = step + 1;
-        S.hiderTeamReward[w] = 1.f;
-        return;
+    uint32_t ep, world_id;
+    if (LOAD) {
+        ep = ck->episode_key[0]; world_id = ck->episode_key[1];
+    } else {
+        // ---- resetEnvironment + initEpisodeRNG (sim.cpp:105-159)
+        S.xReset[w] = 0;
+        ep = S.curWorldEpisode[w];
+        S.curWorldEpisode[w] = ep + 1;
+        world_id = (uint32_t)(S.worldOffset + w);
     }
-    // ---- resetEnvironment + initEpisodeRNG (sim.cpp:105-159)
-    S.xReset[w] = 0;
-    uint32_t ep = S.curWorldEpisode[w];
-    S.curWorldEpisode[w] = ep + 1;
-    const uint32_t world_id = (uint32_t)(S.worldOffset + w);
+    S.epKeyA[w] = ep; S.epKeyB[w] = world_id;
     RNG erng; erng.k = threefry2x32(S.initKey, ep, world_id); erng.count = 0;
-    int nh = erng.sampleI32(S.minHiders, S.maxHiders + 1);
+    int nh = erng.sampleI32(S.minHiders, S.maxHiders + 1);     // burned on load (sim.cpp:976-980)
     int ns = erng.sampleI32(S.minSeekers, S.maxSeekers + 1);
+    if (LOAD) {        // counts outside the build's capacities are clamped (the reference only asserts)
+        const int capH = S.A < 3 ? S.A : 3;
+        nh = ck->num_hiders < 0 ? 0 : (ck->num_hiders > capH ? capH : ck->num_hiders);
+        const int capS = S.A - nh < 3 ? S.A - nh : 3;
+        ns = ck->num_seekers < 0 ? 0 : (ck->num_seekers > capS ? capS : ck->num_seekers);
+    }
     RandKey lvl = erng.randKey();
     if ((S.flags & FLAG_USE_FIXED_WORLD) == FLAG_USE_FIXED_WORLD) lvl = {0u, 0u};
 
@@ -341,13 +349,13 @@ __global__ void __launch_bounds__(64) k_reset(SimState S) {
         g.resp[i] = RESP_STATIC; g.owner[i] = OWNER_NONE; g.lin[i] = {0.f, 0.f, 0.f};
     }
     RNG lrng; lrng.k = lvl; lrng.count = 0;
-    if (level == 1) gen_training(g, lrng, erng, S.flags, nh, ns);
+    if (LOAD || level == 1) gen_training(g, lrng, erng, S.flags, nh, ns);
     else gen_debug(g, level);
 
     // ---- write back
     S.rngKeyA[w] = erng.k.a; S.rngKeyB[w] = erng.k.b; S.rngCount[w] = erng.count;
-    S.curEpisodeStep[w] = 0;
-    S.hiderTeamReward[w] = 1.f;
+    S.curEpisodeStep[w] = LOAD ? ck->episode_step : 0;
+    if (!LOAD) S.hiderTeamReward[w] = 1.f;        // resetSystem sim.cpp:199; the load graph leaves it alone
     S.numWalls[w] = g.numWalls; S.numPlanes[w] = g.numPlanes;
     for (int i = 0; i < g.numWalls; ++i) {
         S.walls[(0 * kMaxWalls + i) * N + w] = g.wcx[i]; S.walls[(1 * kMaxWalls + i) * N + w] = g.wcy[i];
@@ -392,6 +400,112 @@ __global__ void __launch_bounds__(64) k_reset(SimState S) {
             S.xSelfMask[row] = 0.f;
         }
     }
+    if (!LOAD) return;
+    // ---- loadCheckpointSystem sim.cpp:973, 985-1043
+    S.runningScores[0 * N + w] = ck->running_scores[0]; S.runningScores[1 * N + w] = ck->running_scores[1];
+    auto put_body = [&](int slot, const float *b) {       // pos3 rot4 lin3 ang3
+        for (int c = 0; c < 3; ++c) {
+            S.bpos[(c * kNumDSlots + slot) * N + w] = b[c];
+            S.blin[(c * kNumDSlots + slot) * N + w] = b[7 + c];
+            S.bang[(c * kNumDSlots + slot) * N + w] = b[10 + c];
+        }
+        for (int c = 0; c < 4; ++c) S.brot[(c * kNumDSlots + slot) * N + w] = b[3 + c];
+    };
+    const int nb = ck->num_boxes < 0 ? 0 : (ck->num_boxes > g.numActiveBoxes ? g.numActiveBoxes : ck->num_boxes);
+    const int nr = ck->num_ramps < 0 ? 0 : (ck->num_ramps > g.numActiveRamps ? g.numActiveRamps : ck->num_ramps);
+    for (int i = 0; i < nb + nr; ++i) {
+        const hs_ckpt_object &o = i < nb ? ck->boxes[i] : ck->ramps[i - nb];
+        const int slot = i < nb ? i : kRampSlot0 + (i - nb);
+        put_body(slot, o.pos);
+        S.bmeta[slot * N + w] = meta_pack(g.obj[slot], o.is_locked ? RESP_STATIC : RESP_DYNAMIC, (int)(o.team & 3u));
+    }
+    for (int i = 0; i < g.numHiders + g.numSeekers; ++i) {
+        const hs_ckpt_agent &a = ck->agents[i];
+        const int ai = i < g.numHiders ? g.hiders[i] : g.seekers[i - g.numHiders];
+        put_body(kAgentSlot0 + ai, a.pos);
+        if (a.grab_idx >= 0 && a.grab_idx < nb + nr) {
+            S.grabOther[ai * N + w] = a.grab_idx < nb ? a.grab_idx : kRampSlot0 + (a.grab_idx - nb);
+            float gd[kGrabWords] = {a.grab_r2[0], a.grab_r2[1], a.grab_r2[2],
+                                    a.attach_rot2[0], a.attach_rot2[1], a.attach_rot2[2], a.attach_rot2[3], a.separation,
+                                    a.grab_r1[0], a.grab_r1[1], a.grab_r1[2],
+                                    a.attach_rot1[0], a.attach_rot1[1], a.attach_rot1[2], a.attach_rot1[3]};
+            for (int c = 0; c < kGrabWords; ++c) S.grabData[(c * kMaxAgents + ai) * N + w] = gd[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_reset(SimState S) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= S.N) return;
+    int level = S.xReset[w];
+    const int step = S.curEpisodeStep[w];
+    if ((S.flags & FLAG_IGNORE_EPISODE_LENGTH) != FLAG_IGNORE_EPISODE_LENGTH && step == kEpisodeLen - 1) level = 1;
+    if (level == 0) {
+        S.curEpisodeStep[w] = step + 1;
+        S.hiderTeamReward[w] = 1.f;
+        return;
+    }
+    regenerate_world<false>(S, w, level, nullptr);
+}
+
+// LoadCheckpoints graph, first node (sim.cpp:1324-1329); the trigger is left at 1 as sim.cpp:963 does.
+__global__ void __launch_bounds__(64) k_load_ckpt(SimState S) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= S.N) return;
+    if (S.xCkptCtrl[w] == 0) return;
+    S.xCkptCtrl[w] = 1;
+    regenerate_world<true>(S, w, 1, (const hs_checkpoint *)S.xCkpt + w);
+}
+
+// SaveCheckpoints graph (sim.cpp:1315-1322): saveCheckpointSystem sim.cpp:1046-1137.
+__global__ void __launch_bounds__(64) k_save_ckpt(SimState S) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = S.N;
+    if (w >= N) return;
+    if (S.xCkptCtrl[w] == 0) return;
+    S.xCkptCtrl[w] = 0;
+    hs_checkpoint *ck = (hs_checkpoint *)S.xCkpt + w;
+    uint32_t *raw = (uint32_t *)ck;
+    for (int i = 0; i < (int)(sizeof(hs_checkpoint) / 4); ++i) raw[i] = 0u;
+    ck->episode_key[0] = S.epKeyA[w]; ck->episode_key[1] = S.epKeyB[w];
+    ck->running_scores[0] = S.runningScores[0 * N + w]; ck->running_scores[1] = S.runningScores[1 * N + w];
+    ck->episode_step = S.curEpisodeStep[w];
+    const int cnt = S.counts[w], teams = S.teams[w];
+    const int nh = cnt_hiders(cnt), ns = cnt_seekers(cnt), nb = cnt_boxes(cnt), nr = cnt_ramps(cnt);
+    auto get_body = [&](int slot, float *b) {
+        for (int c = 0; c < 3; ++c) {
+            b[c] = S.bpos[(c * kNumDSlots + slot) * N + w];
+            b[7 + c] = S.blin[(c * kNumDSlots + slot) * N + w];
+            b[10 + c] = S.bang[(c * kNumDSlots + slot) * N + w];
+        }
+        for (int c = 0; c < 4; ++c) b[3 + c] = S.brot[(c * kNumDSlots + slot) * N + w];
+    };
+    for (int i = 0; i < nh + ns; ++i) {
+        const int ai = i < nh ? team_hider(teams, i) : team_seeker(teams, i - nh);
+        hs_ckpt_agent &a = ck->agents[i];
+        get_body(kAgentSlot0 + ai, a.pos);
+        a.grab_idx = -1;
+        const int other = S.grabOther[ai * N + w];
+        if (other >= 0) {
+            float gd[kGrabWords];
+            for (int c = 0; c < kGrabWords; ++c) gd[c] = S.grabData[(c * kMaxAgents + ai) * N + w];
+            for (int c = 0; c < 3; ++c) { a.grab_r2[c] = gd[c]; a.grab_r1[c] = gd[8 + c]; }
+            for (int c = 0; c < 4; ++c) { a.attach_rot2[c] = gd[3 + c]; a.attach_rot1[c] = gd[11 + c]; }
+            a.separation = gd[7];
+            if (other < nb) a.grab_idx = other;
+            else if (other >= kRampSlot0 && other < kRampSlot0 + nr) a.grab_idx = other - kRampSlot0 + nb;
+        }
+    }
+    ck->num_hiders = nh; ck->num_seekers = ns;
+    for (int i = 0; i < nb + nr; ++i) {
+        const int slot = i < nb ? i : kRampSlot0 + (i - nb);
+        hs_ckpt_object &o = i < nb ? ck->boxes[i] : ck->ramps[i - nb];
+        get_body(slot, o.pos);
+        const int m = S.bmeta[slot * N + w];
+        o.team = (uint32_t)meta_owner(m);
+        o.is_locked = meta_resp(m) == RESP_STATIC ? 1 : 0;
+    }
+    ck->num_boxes = nb; ck->num_ramps = nr;
 }
 
 }  // namespace hs

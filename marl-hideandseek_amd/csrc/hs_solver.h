@@ -19,7 +19,7 @@ static_assert(sizeof(ManDD) == 144 && sizeof(ManS) == 112, "manifold layout");
 struct ActWorld {
     WorldGeom g;
     int grabOther[kMaxAgents];
-    float grabData[kMaxAgents][8];
+    float grabData[kMaxAgents][kGrabWords];
     int actGL[kMaxAgents];
     int teams;
 };
@@ -208,6 +208,8 @@ HSD void action_system(ActWorld &pw, int A_) {
                         gd[0] = r2.x; gd[1] = r2.y; gd[2] = r2.z;
                         gd[3] = at2.w; gd[4] = at2.x; gd[5] = at2.y; gd[6] = at2.z;
                         gd[7] = t - 1.25f;
+                        gd[8] = 0.f; gd[9] = 1.25f; gd[10] = 0.5f;            // r1 = 1.25 fwd + 0.5 up (sim.cpp:343-344)
+                        gd[11] = 1.f; gd[12] = 0.f; gd[13] = 0.f; gd[14] = 0.f;  // attachRot1 = identity
                     }
                 }
             }

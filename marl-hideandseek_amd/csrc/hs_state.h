@@ -37,6 +37,7 @@ struct SimState {
     // --- world scalars (Sim fields src/sim.hpp:326-362 and singletons :105-121)
     uint32_t *curWorldEpisode;   // [N]
     uint32_t *rngKeyA, *rngKeyB, *rngCount;   // episode RNG
+    uint32_t *epKeyA, *epKeyB;   // [N] curEpisodeRNDCounter = {episode index, global world id} (sim.cpp:107-111)
     int *curEpisodeStep;         // [N]
     float *hiderTeamReward;      // [N]
     int *counts;    // [N] numHiders | numSeekers<<4 | numActiveAgents<<8 | numActiveBoxes<<12 | numActiveRamps<<16 | seekersFirst<<20
@@ -44,12 +45,14 @@ struct SimState {
     int *runningScores;          // [2][N]
     // --- grab joints, one per agent slot
     int *grabOther;        // [6][N]  D-slot or -1
-    float *grabData;       // [8][6][N]  r2 xyz, attach2 wxyz, separation
+    float *grabData;       // [kGrabWords][6][N]  r2 xyz, attach2 wxyz, separation, r1 xyz, attach1 wxyz
 
     // --- exported columns (AoS)
     int32_t *xReset, *xPrep, *xAction, *xSelfType, *xSeed, *xDone, *xPolicy;
     float *xSelfObs, *xSelfMask, *xAgentObs, *xBoxObs, *xRampObs, *xVisAgents, *xVisBoxes, *xVisRamps;
     float *xLidar, *xReward, *xGlobalPos, *xEpisodeResult;
+    int32_t *xCkptCtrl;    // [N]  CheckpointControl::trigger (sim.hpp:279-281)
+    uint8_t *xCkpt;        // [N][sizeof(hs_checkpoint)]  (include/hideseek.h, sim.hpp:283-313)
     // --- substep scratch of the physics pipeline (hs_k_pipeline.h), all SoA across worlds
     float *bppos, *bprot;  // [3][17][N], [4][17][N]  pose at the start of the substep
     float *blo, *bhi;      // [3][17][N]  hull AABBs

@@ -151,8 +151,14 @@ def _load():
     L.hs_create.restype = C.c_int32
     L.hs_destroy.argtypes = [C.c_void_p]
     L.hs_destroy.restype = None
-    for n in ("hs_init", "hs_step"):
+    for n in ("hs_init", "hs_step", "hs_save_checkpoints", "hs_load_checkpoints"):
         getattr(L, n).argtypes = [C.c_void_p]
+        getattr(L, n).restype = C.c_int32
+    for n in ("hs_save_checkpoint", "hs_load_checkpoint"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_int32]
+        getattr(L, n).restype = C.c_int32
+    for n in ("hs_jax_init", "hs_jax_step", "hs_jax_save_checkpoints", "hs_jax_load_checkpoints"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         getattr(L, n).restype = C.c_int32
     L.hs_step_async.argtypes = [C.c_void_p, C.c_void_p]
     L.hs_step_async.restype = C.c_int32
@@ -282,10 +288,56 @@ class HideAndSeekSimulator:
     def set_action(self, agent_idx, x, y, r, g, l):
         _check(self._L.hs_set_action(self._h, int(agent_idx), int(x), int(y), int(r), int(g), int(l)))
 
+    # ---- checkpoints: Manager::saveCheckpoint / loadCheckpoint / loadCheckpoints (mgr.cpp:905-985) ----
+    def save_checkpoint(self, world_idx):
+        _check(self._L.hs_save_checkpoint(self._h, int(world_idx)))
+
+    def load_checkpoint(self, world_idx):
+        _check(self._L.hs_load_checkpoint(self._h, int(world_idx)))
+
+    def load_checkpoints(self):
+        """Run the LoadCheckpoints graph for the triggers currently in ckpt_ctrl_tensor()."""
+        _check(self._L.hs_load_checkpoints(self._h))
+
+    def save_checkpoints(self):
+        """Run the SaveCheckpoints graph for the triggers currently in ckpt_ctrl_tensor()."""
+        _check(self._L.hs_save_checkpoints(self._h))
+
+    # ---- the XLA-callable stream functions behind sim.jax() (bindings.cpp:97-118, mgr.cpp:362-436) ----
+    # `buffers`: device pointers (ints) or objects with .data_ptr(), in the reference's order
+    # (include/hideseek.h hs_jax_*).  Nothing is synchronised except stream_init.
+    def _stream_call(self, fn, hip_stream, buffers):
+        ptrs = [int(b.data_ptr()) if hasattr(b, "data_ptr") else int(b) for b in buffers]
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        _check(fn(self._h, C.c_void_p(int(hip_stream)), arr))
+
+    def stream_init(self, hip_stream, buffers):
+        if len(buffers) != 11:
+            raise ValueError("stream_init takes the 11 observation buffers")
+        self._stream_call(self._L.hs_jax_init, hip_stream, buffers)
+
+    def stream_step(self, hip_stream, buffers):
+        if len(buffers) != 17:
+            raise ValueError("stream_step takes actions, resets, policy_assignments, 11 observation buffers, "
+                             "rewards, dones, episode_results")
+        self._stream_call(self._L.hs_jax_step, hip_stream, buffers)
+
+    def stream_save_checkpoints(self, hip_stream, buffers):
+        if len(buffers) != 2:
+            raise ValueError("stream_save_checkpoints takes ckpt_ctrl, ckpts")
+        self._stream_call(self._L.hs_jax_save_checkpoints, hip_stream, buffers)
+
+    def stream_load_checkpoints(self, hip_stream, buffers):
+        if len(buffers) != 13:
+            raise ValueError("stream_load_checkpoints takes ckpt_ctrl, ckpts, 11 observation buffers")
+        self._stream_call(self._L.hs_jax_load_checkpoints, hip_stream, buffers)
+
     def jax(self, jax_gpu):
         raise NotImplementedError(
-            "sim.jax(): the XLA custom-call wrapper is not built in this round (no jaxlib on the target, "
-            "SURVEY §7 H8); use Tensor.to_jax()/DLPack and step_async(stream)")
+            "sim.jax(): the XLA custom-call registration needs jaxlib, which is not on the target (SURVEY §7 H8). "
+            "The stream functions it would register exist natively (hs_jax_init/step/save_checkpoints/"
+            "load_checkpoints, exposed as stream_init/stream_step/stream_save_checkpoints/stream_load_checkpoints); "
+            "Tensor.to_jax() hands the buffers over through DLPack.")
 
     # ---- parity-test hooks (include/hideseek.h hs_debug_dump_*) ----
     def debug_bodies(self):

@@ -41,7 +41,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.hsref_create.restype = C.c_void_p
         L.hsref_create.argtypes = [C.POINTER(_Cfg)]
-        for n in ("hsref_destroy", "hsref_init", "hsref_step"):
+        for n in ("hsref_destroy", "hsref_init", "hsref_step", "hsref_save_checkpoints", "hsref_load_checkpoints"):
             getattr(L, n).argtypes = [C.c_void_p]
             getattr(L, n).restype = None
         L.hsref_agents_per_world.argtypes = [C.c_void_p]
@@ -90,6 +90,8 @@ TENSORS = {
     "global_positions": (16, np.float32, (17, 2), False),
     "policy_assignments": (17, np.int32, (1,), True),
     "episode_result": (18, np.float32, (2,), False),
+    "ckpt_ctrl": (19, np.int32, (1,), False),          # CheckpointControl::trigger (the u8 [N,4] tensor viewed as i32)
+    "ckpt": (20, np.uint8, (1392,), False),            # Checkpoint bytes (oracle/hs_ref_ckpt.hpp)
 }
 
 
@@ -125,9 +127,17 @@ class RefSim:
         rows = self.N * self.A if per_agent else self.N
         ptr = lib().hsref_tensor(self._h, eid)
         n = rows * int(np.prod(tail))
-        ctype = C.c_int32 if dt == np.int32 else C.c_float
+        ctype = {np.int32: C.c_int32, np.float32: C.c_float, np.uint8: C.c_uint8}[dt]
         arr = np.ctypeslib.as_array((ctype * n).from_address(ptr))
         return arr.reshape((rows,) + tail)
+
+    def save_checkpoints(self):
+        """SaveCheckpoints task graph for the worlds whose ckpt_ctrl trigger is set (sim.cpp:1315-1322)."""
+        lib().hsref_save_checkpoints(self._h)
+
+    def load_checkpoints(self):
+        """LoadCheckpoints task graph (sim.cpp:1324-1333): restore triggered worlds, refresh observations."""
+        lib().hsref_load_checkpoints(self._h)
 
     def bodies(self):
         b = np.zeros((self.N, 17, 13), np.float32)

@@ -2,6 +2,7 @@
 // Plain C entry points so tests/ and bench.py's cpu_baseline leg can drive the CPU
 // restatement through ctypes.  Export ids mirror ExportID (src/sim.hpp:45-68).
 #include "hs_ref_sim.hpp"
+#include "hs_ref_ckpt.hpp"
 
 using namespace hsref;
 
@@ -31,6 +32,8 @@ void hsref_destroy(void *p) { delete (Sim *)p; }
 void hsref_init(void *p) { ((Sim *)p)->init(); }
 void hsref_step(void *p) { ((Sim *)p)->step(); }
 int32_t hsref_agents_per_world(void *p) { return ((Sim *)p)->A; }
+void hsref_save_checkpoints(void *p) { sim_save_checkpoints(*(Sim *)p); }
+void hsref_load_checkpoints(void *p) { sim_load_checkpoints(*(Sim *)p); }
 
 // ExportID order: Reset, PrepCounter, Action, SelfObs, SelfType, SelfMask, AgentObsData,
 // BoxObsData, RampObsData, AgentVisMasks, BoxVisMasks, RampVisMasks, Lidar, Seed, Reward, Done,
@@ -45,6 +48,7 @@ void *hsref_tensor(void *p, int32_t id) {
     case 12: return s->ex.lidar; case 13: return s->ex.seed; case 14: return s->ex.reward;
     case 15: return s->ex.done; case 16: return s->ex.globalPos; case 17: return s->ex.policy;
     case 18: return s->ex.episodeResult;
+    case 19: return s->s_ckptCtrl.data(); case 20: return s->s_ckpt.data();
     default: return nullptr;
     }
 }

@@ -346,12 +346,15 @@ public:
     std::vector<int32_t> s_reset, s_prep, s_action, s_selfType, s_seed, s_done, s_policy;
     std::vector<float> s_selfObs, s_selfMask, s_agentObs, s_boxObs, s_rampObs, s_visAgents,
         s_visBoxes, s_visRamps, s_lidar, s_reward, s_globalPos, s_episodeResult;
+    std::vector<int32_t> s_ckptCtrl;            // CheckpointControl::trigger per world (sim.hpp:279-281)
+    std::vector<uint8_t> s_ckpt;                // Checkpoint per world (hs_ref_ckpt.hpp)
 
     explicit Sim(const Config &c) : cfg(c) {
         A = c.maxHiders + c.maxSeekers;
         initKey = rand_init_key(c.randSeed);
         int N = c.numWorlds, R = N * A;
         worlds.resize(N);
+        s_ckptCtrl.assign(N, 0); s_ckpt.assign((size_t)N * 1392, 0);
         auto mk_i = [](std::vector<int32_t> &v, size_t n) { v.assign(n, 0); return v.data(); };
         auto mk_f = [](std::vector<float> &v, size_t n) { v.assign(n, 0.f); return v.data(); };
         ex.A = A;
