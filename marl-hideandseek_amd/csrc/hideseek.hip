@@ -99,7 +99,7 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
             // packed kernels: grid-stride, sized so the usual item counts (~2.3 pairs, ~1.5 wall bodies,
             // ~0.3 body-body worlds per world) finish in a single pass
             const int gw = (n + 63) / 64;
-            const dim3 gridSat(gw * 4), gridWall(gw * 3), gridDD(gw * 4);      // k_dd: 8 lanes per world
+            const dim3 gridSat(gw * 4), gridDD(gw * 4);      // k_dd: 8 lanes per world
             hipLaunchKernelGGL(hs::k_pre, gridWorld, dim3(256), 0, cs, C);
             for (int sub = 0; sub < 4; ++sub) {
                 const int par = sub & 1;
@@ -107,11 +107,9 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
                 hipLaunchKernelGGL(hs::k_detect, dim3((n + 63) / 64), dim3(1024), 0, cs, C, NS, par);
                 hipLaunchKernelGGL(hs::k_sat, gridSat, dim3(64), 0, cs, C, par);
                 hipLaunchKernelGGL(hs::k_dd<true>, gridDD, dim3(64), 0, cs, C, par);
-                hipLaunchKernelGGL(hs::k_ground_pos, gridBody, dim3(256), 0, cs, C, NS);
-                hipLaunchKernelGGL(hs::k_walls_pos, gridWall, dim3(64), 0, cs, C, par);
+                hipLaunchKernelGGL(hs::k_body_pos, gridBody, dim3(256), 0, cs, C, NS);
                 hipLaunchKernelGGL(hs::k_dd<false>, gridDD, dim3(64), 0, cs, C, par);
-                hipLaunchKernelGGL(hs::k_ground_vel, gridBody, dim3(256), 0, cs, C, NS);
-                hipLaunchKernelGGL(hs::k_walls_vel, gridWall, dim3(64), 0, cs, C, par);
+                hipLaunchKernelGGL(hs::k_body_vel, gridBody, dim3(256), 0, cs, C, NS);
             }
             hipLaunchKernelGGL(hs::k_post, gridWorld, dim3(256), 0, cs, C);
             if (nch > 1) { HS_HIP(hipEventRecord(s->evJoin[c], cs)); HS_HIP(hipStreamWaitEvent(strm, s->evJoin[c], 0)); }

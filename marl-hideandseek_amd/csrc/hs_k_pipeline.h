@@ -77,8 +77,10 @@ HSD void wave_push(int *list, int *counter, int value, bool pred) {
     if (pred) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
-// global ground-manifold word: np | vertex indices << 4 | hasStaticCandidates << 31
+// per-body manifold word: ground np | ground vertex indices << 4 | first static candidate << 16 |
+// static candidate count << 21 | hasStaticCandidates << 30
 constexpr int kGndHasWall = 1 << 30;
+constexpr int kGndScBegShift = 16, kGndScCntShift = 21;
 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) {
@@ -204,11 +206,10 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
     // ---- reserve space in the three global work lists: wave scans, block scan, one atomic per list
     const int lane = tid & 63, wv = tid >> 6;
     bool push_ddw = false;
-    int n_wall = 0;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) { push_ddw |= add[jb] > 0 && bdd[jb] == 0; n_wall += asc[jb] > 0 ? 1 : 0; }
+    for (int jb = 0; jb < 2; ++jb) push_ddw |= add[jb] > 0 && bdd[jb] == 0;
     push_ddw = push_ddw && wok && S.wflags[w] == 0;
-    int mine[3] = {tot_items, n_wall, push_ddw ? 1 : 0};
+    int mine[3] = {tot_items, 0, push_ddw ? 1 : 0};
     int incl[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -226,7 +227,6 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
     }
     __syncthreads();
     int gbase = bbase[0] + wtot[0][wv] + incl[0] - mine[0];
-    int wbase2 = bbase[1] + wtot[1][wv] + incl[1] - mine[1];
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
         const int slot = l + jb * G;
@@ -247,7 +247,6 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
             S.satList[gbase++] = (w << 6) | 32 | (bsc[jb] + i);
             ++i;
         }
-        if (asc[jb] > 0) S.wallList[wbase2++] = (int)(((unsigned)w << 15) | (bsc[jb] << 10) | (asc[jb] << 5) | slot);
     }
     if (push_ddw) S.ddwList[bbase[2] + wtot[2][wv] + incl[2] - 1] = w;
     __syncthreads();
@@ -259,7 +258,7 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
         if (!wok || slot >= NS) continue;
         const int meta = dw.meta[slot];
         if (meta == 0) continue;
-        int gword = asc[jb] > 0 ? kGndHasWall : 0;
+        int gword = asc[jb] > 0 ? (kGndHasWall | (bsc[jb] << kGndScBegShift) | (asc[jb] << kGndScCntShift)) : 0;
         if (meta_resp(meta) == RESP_DYNAMIC && npl >= 1) {
             const int obj = meta_obj(meta);
             HullRef hb = hull_ref_body(obj, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w));
@@ -491,7 +490,12 @@ __global__ void __launch_bounds__(64) k_dd(SimState S, int par) {
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ground_pos(SimState S, int NS) {
+// Static contacts of one body, in the oracle's order: ground manifold, then the body's other static
+// candidates (extra planes, walls by index) — one thread per body, slot-major.  The wall part runs on
+// the few lanes whose body has candidates; a packed per-body kernel was tried first and lost: those
+// kernels are bound by the latency of one lane's sequential solve, not by lane utilisation, so the
+// extra launch (drain + dispatch + reloading the body) cost more than the idle lanes do here.
+__global__ void __launch_bounds__(256) k_body_pos(SimState S, int NS) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int N = S.N;
     if (t >= NS * S.wcnt) return;
@@ -501,7 +505,6 @@ __global__ void __launch_bounds__(256) k_ground_pos(SimState S, int NS) {
     const int gword = S.gman[slot * N + w];
     const int np = gword & 7;
     const bool has_wall = (gword & kGndHasWall) != 0;
-    if (np == 0 && has_wall) return;          // nothing to do here; k_walls_pos derives the velocity
     const int obj = meta_obj(meta);
     BodyS me, none;
     gbody_load(S, w, slot, me);
@@ -514,41 +517,11 @@ __global__ void __launch_bounds__(256) k_ground_pos(SimState S, int NS) {
                                                           V3{0.f, 0.f, 0.f}, S.goff[bidx(S, j, slot, w)], gmuS);
             S.glam[bidx(S, j, slot, w)] += lam;
         }
-        gbody_store_pose(S, w, slot, me);
     }
-    if (!has_wall) { derive_velocity(me); gbody_store_vel(S, w, slot, me); }
-}
-
-__global__ void __launch_bounds__(256) k_ground_vel(SimState S, int NS) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int N = S.N;
-    if (t >= NS * S.wcnt) return;
-    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
-    const int meta = S.bmeta[slot * N + w];
-    if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
-    const int gword = S.gman[slot * N + w];
-    const int np = gword & 7;
-    if (np == 0) return;
-    const int obj = meta_obj(meta);
-    BodyS me, none;
-    gbody_load(S, w, slot, me);
-    const V3 gn = -V3{S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
-    const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
-#pragma unroll 1
-    for (int j = 0; j < np; ++j)
-        solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (gword >> (4 + 3 * j)) & 7), V3{0.f, 0.f, 0.f},
-                                    S.glam[bidx(S, j, slot, w)], gmuD);
-    gbody_store_vel(S, w, slot, me);
-}
-
-__global__ void __launch_bounds__(64) k_walls_pos(SimState S, int par) {
-    const int total = S.counters[par * 4 + 1];
-    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
-        const unsigned item = (unsigned)S.wallList[it];
-        const int w = item >> 15, bsc = (item >> 10) & 31, asc = (item >> 5) & 31, slot = item & 31;
+    if (has_wall) {
         ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
-        BodyS me, none;
-        gbody_load(S, w, slot, me);
+        const int bsc = (gword >> kGndScBegShift) & 31, asc = (gword >> kGndScCntShift) & 31;
+#pragma unroll 1
         for (int k = bsc; k < bsc + asc; ++k) {       // the body's candidates, already in solve order
             ManS m = wsSC[k];
             if (m.np <= 0) continue;
@@ -558,19 +531,38 @@ __global__ void __launch_bounds__(64) k_walls_pos(SimState S, int par) {
             for (int j = 0; j < 4; ++j)
                 if (j < m.np) wsSC[k].lam[j] = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
         }
-        derive_velocity(me);
-        gbody_store_pose(S, w, slot, me); gbody_store_vel(S, w, slot, me);
     }
+    if (np > 0 || has_wall) gbody_store_pose(S, w, slot, me);
+    derive_velocity(me);
+    gbody_store_vel(S, w, slot, me);
 }
 
-__global__ void __launch_bounds__(64) k_walls_vel(SimState S, int par) {
-    const int total = S.counters[par * 4 + 1];
-    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
-        const unsigned item = (unsigned)S.wallList[it];
-        const int w = item >> 15, bsc = (item >> 10) & 31, asc = (item >> 5) & 31, slot = item & 31;
+__global__ void __launch_bounds__(256) k_body_vel(SimState S, int NS) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N = S.N;
+    if (t >= NS * S.wcnt) return;
+    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
+    const int meta = S.bmeta[slot * N + w];
+    if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
+    const int gword = S.gman[slot * N + w];
+    const int np = gword & 7;
+    const bool has_wall = (gword & kGndHasWall) != 0;
+    if (np == 0 && !has_wall) return;
+    const int obj = meta_obj(meta);
+    BodyS me, none;
+    gbody_load(S, w, slot, me);
+    if (np > 0) {
+        const V3 gn = -V3{S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
+        const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+#pragma unroll 1
+        for (int j = 0; j < np; ++j)
+            solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (gword >> (4 + 3 * j)) & 7), V3{0.f, 0.f, 0.f},
+                                        S.glam[bidx(S, j, slot, w)], gmuD);
+    }
+    if (has_wall) {
         const ManS *const wsSC = (const ManS *)S.wsSC + (size_t)w * kMaxSCand;
-        BodyS me, none;
-        gbody_load(S, w, slot, me);
+        const int bsc = (gword >> kGndScBegShift) & 31, asc = (gword >> kGndScCntShift) & 31;
+#pragma unroll 1
         for (int k = bsc; k < bsc + asc; ++k) {
             const ManS m = wsSC[k];
             if (m.np <= 0) continue;
@@ -580,8 +572,8 @@ __global__ void __launch_bounds__(64) k_walls_vel(SimState S, int par) {
             for (int j = 0; j < 4; ++j)
                 if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
         }
-        gbody_store_vel(S, w, slot, me);
     }
+    gbody_store_vel(S, w, slot, me);
 }
 
 // ------------------------------------------------------------------------------------------
