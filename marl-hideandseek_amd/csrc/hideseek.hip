@@ -103,13 +103,14 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
             hipLaunchKernelGGL(hs::k_pre, gridWorld, dim3(256), 0, cs, C);
             for (int sub = 0; sub < 4; ++sub) {
                 const int par = sub & 1;
-                hipLaunchKernelGGL(hs::k_integrate, gridBody, dim3(256), 0, cs, C, NS, par);
+                if (sub == 0) hipLaunchKernelGGL(hs::k_integrate, gridBody, dim3(256), 0, cs, C, NS, par);
                 hipLaunchKernelGGL(hs::k_detect, dim3((n + 63) / 64), dim3(1024), 0, cs, C, NS, par);
                 hipLaunchKernelGGL(hs::k_sat, gridSat, dim3(64), 0, cs, C, par);
                 hipLaunchKernelGGL(hs::k_dd<true>, gridDD, dim3(64), 0, cs, C, par);
                 hipLaunchKernelGGL(hs::k_body_pos, gridBody, dim3(256), 0, cs, C, NS);
                 hipLaunchKernelGGL(hs::k_dd<false>, gridDD, dim3(64), 0, cs, C, par);
-                hipLaunchKernelGGL(hs::k_body_vel, gridBody, dim3(256), 0, cs, C, NS);
+                if (sub < 3) hipLaunchKernelGGL(hs::k_body_vel<true>, gridBody, dim3(256), 0, cs, C, NS, par ^ 1);
+                else hipLaunchKernelGGL(hs::k_body_vel<false>, gridBody, dim3(256), 0, cs, C, NS, 0);
             }
             hipLaunchKernelGGL(hs::k_post, gridWorld, dim3(256), 0, cs, C);
             if (nch > 1) { HS_HIP(hipEventRecord(s->evJoin[c], cs)); HS_HIP(hipStreamWaitEvent(strm, s->evJoin[c], 0)); }

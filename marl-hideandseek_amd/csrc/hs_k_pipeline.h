@@ -83,27 +83,14 @@ constexpr int kGndHasWall = 1 << 30;
 constexpr int kGndScBegShift = 16, kGndScCntShift = 21;
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+// Start of a substep for one body: remember the pose, semi-implicit Euler step (gravity, agent force
+// and torque, gyroscopic term), refresh the hull AABB.
+HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q rot, V3 lin, V3 ang) {
     const int N = S.N;
-    if (t == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }   // next substep's lists
-    if (t >= NS * S.wcnt) return;
-    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
-    if (slot == 0) {
-        S.ndd[w] = 0; S.nsc[w] = 0;
-        bool grab = false;
-        for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther[a * N + w] >= 0;
-        S.wflags[w] = grab ? 1 : 0;
-        if (grab) S.ddwList[atomicAdd(&S.counters[par * 4 + 2], 1)] = w;
-    }
-    const int meta = S.bmeta[slot * N + w];
-    if (meta == 0) return;
     const int obj = meta_obj(meta);
-    V3 pos = gld3(S.bpos, S, slot, w); Q rot = gld4(S.brot, S, slot, w);
     gst3(S.bppos, S, slot, w, pos); gst4(S.bprot, S, slot, w, rot);
     if (meta_resp(meta) == RESP_DYNAMIC) {
         const float h = kSubstepH;
-        V3 lin = gld3(S.blin, S, slot, w), ang = gld3(S.bang, S, slot, w);
         const float invM = obj_inv_mass(obj);
         const V3 invI = obj_inv_inertia(obj);
         V3 force = {0.f, 0.f, 0.f}; float torque_z = 0.f;
@@ -127,6 +114,34 @@ __global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) 
     V3 lo, hi;
     hull_aabb(hull_ref_body(obj, pos, rot), &lo, &hi);
     gst3(S.blo, S, slot, w, lo); gst3(S.bhi, S, slot, w, hi);
+}
+
+// Per-world bookkeeping at the start of substep `par`: clear the candidate counts, queue worlds with a
+// grab joint for k_dd, and (thread 0) clear the list lengths of the following substep.
+HSD void substep_begin(const SimState &S, int t, int slot, int w, int par) {
+    const int N = S.N;
+    if (t == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }
+    if (slot == 0) {
+        S.ndd[w] = 0; S.nsc[w] = 0;
+        bool grab = false;
+        for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther[a * N + w] >= 0;
+        S.wflags[w] = grab ? 1 : 0;
+        if (grab) S.ddwList[atomicAdd(&S.counters[par * 4 + 2], 1)] = w;
+    }
+}
+
+// First substep only; the later substeps are integrated at the end of k_body_vel.
+__global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N = S.N;
+    if (t >= NS * S.wcnt) return;
+    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
+    substep_begin(S, t, slot, w, par);
+    const int meta = S.bmeta[slot * N + w];
+    if (meta == 0) return;
+    V3 lin = {0.f, 0.f, 0.f}, ang = {0.f, 0.f, 0.f};
+    if (meta_resp(meta) == RESP_DYNAMIC) { lin = gld3(S.blin, S, slot, w); ang = gld3(S.bang, S, slot, w); }
+    integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,17 +552,29 @@ __global__ void __launch_bounds__(256) k_body_pos(SimState S, int NS) {
     gbody_store_vel(S, w, slot, me);
 }
 
-__global__ void __launch_bounds__(256) k_body_vel(SimState S, int NS) {
+// Velocity pass over a body's static contacts; with NEXT, also the start of the following substep
+// (parity par_next) for every body, so the body is integrated from registers instead of by a
+// separate launch.
+template <bool NEXT>
+__global__ void __launch_bounds__(256) k_body_vel(SimState S, int NS, int par_next) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int N = S.N;
     if (t >= NS * S.wcnt) return;
     const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
+    if (NEXT) substep_begin(S, t, slot, w, par_next);
     const int meta = S.bmeta[slot * N + w];
-    if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
+    if (meta == 0) return;
+    if (meta_resp(meta) != RESP_DYNAMIC) {
+        if (NEXT) integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), V3{0.f, 0.f, 0.f}, V3{0.f, 0.f, 0.f});
+        return;
+    }
     const int gword = S.gman[slot * N + w];
     const int np = gword & 7;
     const bool has_wall = (gword & kGndHasWall) != 0;
-    if (np == 0 && !has_wall) return;
+    if (np == 0 && !has_wall) {
+        if (NEXT) integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), gld3(S.blin, S, slot, w), gld3(S.bang, S, slot, w));
+        return;
+    }
     const int obj = meta_obj(meta);
     BodyS me, none;
     gbody_load(S, w, slot, me);
@@ -573,7 +600,8 @@ __global__ void __launch_bounds__(256) k_body_vel(SimState S, int NS) {
                 if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
         }
     }
-    gbody_store_vel(S, w, slot, me);
+    if (NEXT) integrate_body(S, w, slot, meta, me.pos, me.rot, me.lin, me.ang);
+    else gbody_store_vel(S, w, slot, me);
 }
 
 // ------------------------------------------------------------------------------------------
