@@ -40,12 +40,8 @@ struct hs_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[3] = {0.f, 0.f, 0.f};
     bool initialised = false;
-    std::vector<hs::SimState> chunks;      // per-chunk views of S (world range + work lists) for the physics pipeline
-    std::vector<hipStream_t> cstreams;
-    hipEvent_t evFork = nullptr;
     bool use_graph = true;                 // env HS_GRAPH=0 disables
     hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> evJoin;
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -84,37 +80,9 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     const int N = S.N;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first && (stages & 1)) {
-        // movement + actionSystem, 4 XPBD substeps (9 kernels each), rewards / dones / episode results.
-        // Worlds are independent, so the batch is cut into chunks that run on their own streams: the
-        // latency-bound packed kernels of one chunk overlap the dense kernels of another.
-        const int NS = hs::kAgentSlot0 + s->A;                 // body slots in use
-        const int nch = (int)s->chunks.size();
-        if (nch > 1) HS_HIP(hipEventRecord(s->evFork, strm));
-        for (int c = 0; c < nch; ++c) {
-            const hs::SimState &C = s->chunks[c];
-            hipStream_t cs = nch > 1 ? s->cstreams[c] : strm;
-            if (nch > 1) HS_HIP(hipStreamWaitEvent(cs, s->evFork, 0));
-            const int n = C.wcnt;
-            const dim3 gridBody((NS * n + 255) / 256), gridWorld((n + 15) / 16);
-            // packed kernels: grid-stride, sized so the usual item counts (~2.3 pairs, ~1.5 wall bodies,
-            // ~0.3 body-body worlds per world) finish in a single pass
-            const int gw = (n + 63) / 64;
-            const dim3 gridSat(gw * 4), gridDD(gw * 4);      // k_dd: 8 lanes per world
-            hipLaunchKernelGGL(hs::k_pre, gridWorld, dim3(256), 0, cs, C);
-            for (int sub = 0; sub < 4; ++sub) {
-                const int par = sub & 1;
-                if (sub == 0) hipLaunchKernelGGL(hs::k_integrate, gridBody, dim3(256), 0, cs, C, NS, par);
-                hipLaunchKernelGGL(hs::k_detect, dim3((n + 63) / 64), dim3(1024), 0, cs, C, NS, par);
-                hipLaunchKernelGGL(hs::k_sat, gridSat, dim3(64), 0, cs, C, par);
-                hipLaunchKernelGGL(hs::k_dd<true>, gridDD, dim3(64), 0, cs, C, par);
-                hipLaunchKernelGGL(hs::k_body_pos, gridBody, dim3(256), 0, cs, C, NS);
-                hipLaunchKernelGGL(hs::k_dd<false>, gridDD, dim3(64), 0, cs, C, par);
-                if (sub < 3) hipLaunchKernelGGL(hs::k_body_vel<true>, gridBody, dim3(256), 0, cs, C, NS, par ^ 1);
-                else hipLaunchKernelGGL(hs::k_body_vel<false>, gridBody, dim3(256), 0, cs, C, NS, 0);
-            }
-            hipLaunchKernelGGL(hs::k_post, gridWorld, dim3(256), 0, cs, C);
-            if (nch > 1) { HS_HIP(hipEventRecord(s->evJoin[c], cs)); HS_HIP(hipStreamWaitEvent(strm, s->evJoin[c], 0)); }
-        }
+        // movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results: one persistent kernel,
+        // a workgroup per kPhysWorlds worlds (hs_k_pipeline.h)
+        hipLaunchKernelGGL(hs::k_physics, dim3((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds), dim3(hs::kPhysThreads), 0, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     if (stages & 2) hipLaunchKernelGGL(hs::k_reset, dim3((N + 63) / 64), dim3(64), 0, strm, S);
@@ -215,8 +183,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.gman, D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
     HS_ALLOC(S.ndd, N); HS_ALLOC(S.nsc, N); HS_ALLOC(S.ddPair, hs::kMaxDDCand * N); HS_ALLOC(S.scPair, hs::kMaxSCand * N);
     HS_ALLOC(S.wflags, N);
-    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.ddwList, 2 * N);
-    HS_ALLOC(S.counters, 8 * 8);
+    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.ddwList, 2 * N);
+    HS_ALLOC(S.counters, 8 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
 #undef HS_ALLOC
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
@@ -231,30 +199,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
         if (hipEventCreate(&e) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipEventCreate failed"); }
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
-    {   // physics chunks (env HS_CHUNKS, default 1: measured on MI355X, 2-4 chunks on separate streams are
-        // 6-25 % slower at 16 000 worlds, eager or graph): contiguous world ranges with their own work lists
-        int nch = 1;
-        if (const char *e = getenv("HS_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 8) nch = v; }
-        if ((size_t)nch > N) nch = 1;
-        S.wbeg = 0; S.wcnt = (int)N;
-        for (int c = 0; c < nch; ++c) {
-            hs::SimState C = S;
-            C.wbeg = (int)((size_t)N * c / nch);
-            C.wcnt = (int)((size_t)N * (c + 1) / nch) - C.wbeg;
-            C.satList = S.satList + (size_t)C.wbeg * (hs::kMaxDDCand + hs::kMaxSCand);
-            C.wallList = S.wallList + (size_t)C.wbeg * D;
-            C.ddwList = S.ddwList + (size_t)C.wbeg * 2;
-            C.counters = S.counters + 8 * c;
-            s->chunks.push_back(C);
-            if (nch > 1) {
-                hipStream_t st; hipEvent_t ev;
-                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
-                s->cstreams.push_back(st); s->evJoin.push_back(ev);
-            }
-        }
-        if (nch > 1 && hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "event creation failed"); }
-    }
+    S.wbeg = 0; S.wcnt = (int)N;
     std::memset(s->exports, 0, sizeof(s->exports));
     const int64_t n = (int64_t)N, r = (int64_t)R;
     set_desc(s, HS_EXPORT_RESET, S.xReset, HS_DTYPE_I32, {n, 1});
@@ -289,9 +234,6 @@ void hs_destroy(hs_sim *s) {
     for (void *p : s->allocs) hipFree(p);
     for (auto &e : s->ev) if (e) hipEventDestroy(e);
     for (auto &e : s->graph_exec) if (e) hipGraphExecDestroy(e);
-    for (auto &e : s->evJoin) hipEventDestroy(e);
-    if (s->evFork) hipEventDestroy(s->evFork);
-    for (auto &st : s->cstreams) hipStreamDestroy(st);
     delete s;
 }
 

@@ -221,17 +221,18 @@ HSD void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3 *c1, V3 *c2) {
 }
 
 // LDS scratch for polygon clipping: two ping-pong polygons of up to 8 vertices per lane, laid out
-// [buffer][vertex][component][lane] so that the 64 lanes of a wave hit 64 different banks (a
+// [buffer][vertex][component][lane] so that the lanes of a wave hit different banks (a
 // per-lane struct of 48 words would be a 16-way bank conflict on every access).
-constexpr int kClipWords = 2 * 8 * 3 * 64;
+constexpr int kClipLanes = 32;          // lanes of a wave that run the convex test (phase_sat)
+constexpr int kClipWords = 2 * 8 * 3 * kClipLanes;
 struct ClipBuf { float *base; int lane; };
 HSD V3 cb_get(const ClipBuf &b, int w, int i) {
-    const float *p = b.base + ((w * 8 + i) * 3) * 64 + b.lane;
-    return {p[0], p[64], p[128]};
+    const float *p = b.base + ((w * 8 + i) * 3) * kClipLanes + b.lane;
+    return {p[0], p[kClipLanes], p[2 * kClipLanes]};
 }
 HSD void cb_set(const ClipBuf &b, int w, int i, V3 v) {
-    float *p = b.base + ((w * 8 + i) * 3) * 64 + b.lane;
-    p[0] = v.x; p[64] = v.y; p[128] = v.z;
+    float *p = b.base + ((w * 8 + i) * 3) * kClipLanes + b.lane;
+    p[0] = v.x; p[kClipLanes] = v.y; p[2 * kClipLanes] = v.z;
 }
 
 // Clip the incident face of I against the side planes of reference face fr of R; keep points on

@@ -1,25 +1,27 @@
-// Physics substep pipeline: PhysicsSystem::setupPhysicsStepTasks (src/sim.cpp:1162-1163; engine
-// source absent — DESIGN.md "Engine decisions") as a sequence of small kernels over the SoA columns.
+// Physics step: movement / actions, PhysicsSystem::setupPhysicsStepTasks (src/sim.cpp:1162-1163; engine
+// source absent — DESIGN.md "Engine decisions") and the reward systems as ONE persistent kernel.
 //
-// Per-body work runs with SLOT-MAJOR lanes: thread t -> slot = t / N, world = t % N, so the 64
-// lanes of a wave hold the same body slot of 64 consecutive worlds: every state access is a
-// coalesced dword load/store of a world-fastest column, lanes share the hull type, and all lanes
-// have work (ground contacts exist for every body).  The sparse work — convex tests of candidate
-// pairs, body-body manifolds, wall manifolds — is compacted into GLOBAL work lists with a
-// wavefront ballot + prefix (one atomic per wave) and then processed one lane per item, so those
-// kernels also run on full waves instead of a few lanes per world.
+// A workgroup of kPhysThreads threads owns kPhysWorlds consecutive worlds for the whole step and walks
+// them through the phases below, separated by workgroup barriers only.  Worlds never interact, so no
+// phase has to wait for the slowest item of the whole batch (which is what a kernel boundary per
+// phase costs: measured on MI355X, every sparse phase then takes as long as its worst wave, 3-4x
+// the average one), and a world's columns stay in the CU's L1 / the XCD's L2 from phase to phase.
+//
+// Per-body work runs with SLOT-MAJOR lanes over the workgroup's worlds: item t -> slot = t / wcnt,
+// world = wbeg + t % wcnt, so the lanes of a wave hold the same body slot of consecutive worlds:
+// coalesced dword accesses of world-fastest columns, lanes share the hull type.  The sparse work —
+// convex tests of candidate pairs, body-body manifolds — is compacted into the workgroup's slice of
+// the work lists (wavefront scan + one atomic per list) and processed one lane (or 8) per item.
 //
 // Substep s:
-//   k_integrate      slot-major   integrate, previous pose, AABB; per-world candidate counters = 0
-//   k_detect         slot-major   all-pairs AABB candidates -> per-world lists + global lists;
+//   integrate        slot-major   (substep 0; later ones happen at the end of body_vel)
+//   detect           16 lanes/world  all-pairs AABB candidates -> per-world lists + work lists;
 //                                 ground-plane manifold of every body
-//   k_sat            per pair     exact convex test -> manifold workspace
-//   k_dd_pos         per world*   joints, then body-body manifolds in (i<j) order   (*worlds that have any)
-//   k_ground_pos     slot-major   ground manifold; velocity derivation for bodies without wall candidates
-//   k_walls_pos      per body*    wall / extra-plane manifolds in static order; velocity derivation
-//   k_dd_vel         per world*   body-body velocity pass
-//   k_ground_vel     slot-major   ground velocity pass
-//   k_walls_vel      per body*    wall velocity pass
+//   sat              per pair     exact convex test -> manifold workspace
+//   dd<pos>          8 lanes/world*  joints, then body-body manifolds in (i<j) order   (*worlds that have any)
+//   body_pos         slot-major   ground manifold, the body's wall / extra-plane manifolds; velocity derivation
+//   dd<vel>          8 lanes/world*  body-body velocity pass
+//   body_vel         slot-major   ground + wall velocity pass; integrate for substep s+1
 // The Gauss-Seidel order and every rounding are the oracle's (joints, body-body in pair order,
 // then per body: ground, walls by static id); candidate lists are unordered and sorted on use.
 #pragma once
@@ -29,6 +31,14 @@
 #include "hs_solver.h"
 
 namespace hs {
+
+constexpr int kPhysThreads = 512;      // 8 waves per workgroup: 2 per SIMD, so the convex test keeps its ~220 VGPRs
+constexpr int kPhysWorlds = 64;        // worlds per workgroup (16 000 worlds -> 250 workgroups on 256 CUs)
+constexpr int kPhysWaves = kPhysThreads / 64;
+
+// List lengths are bumped with atomics (performed in L2) and read by other waves of the workgroup in
+// a later phase: read them past the CU's L1.
+HSD int load_counter(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- SoA accessors ----
 HSD int bidx(const SimState &S, int c, int slot, int w) { return (c * kNumDSlots + slot) * S.N + w; }
@@ -130,18 +140,18 @@ HSD void substep_begin(const SimState &S, int t, int slot, int w, int par) {
     }
 }
 
-// First substep only; the later substeps are integrated at the end of k_body_vel.
-__global__ void __launch_bounds__(256) k_integrate(SimState S, int NS, int par) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+// First substep only; the later substeps are integrated at the end of phase_body_vel.
+HSD void phase_integrate(const SimState &S, int NS, int par) {
     const int N = S.N;
-    if (t >= NS * S.wcnt) return;
-    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
-    substep_begin(S, t, slot, w, par);
-    const int meta = S.bmeta[slot * N + w];
-    if (meta == 0) return;
-    V3 lin = {0.f, 0.f, 0.f}, ang = {0.f, 0.f, 0.f};
-    if (meta_resp(meta) == RESP_DYNAMIC) { lin = gld3(S.blin, S, slot, w); ang = gld3(S.bang, S, slot, w); }
-    integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang);
+    for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
+        const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
+        substep_begin(S, t, slot, w, par);
+        const int meta = S.bmeta[slot * N + w];
+        if (meta == 0) continue;
+        V3 lin = {0.f, 0.f, 0.f}, ang = {0.f, 0.f, 0.f};
+        if (meta_resp(meta) == RESP_DYNAMIC) { lin = gld3(S.blin, S, slot, w); ang = gld3(S.bang, S, slot, w); }
+        integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -154,17 +164,22 @@ struct DetectWorld {
     int ndd, nsc;
 };
 
-// Global list space is reserved with ONE atomic per list per 1024-thread block (a single counter
-// sustains only ~90 atomics/us, so per-wave reservations would dominate this kernel).
-__global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
-    constexpr int G = 16, NT = 1024, WPB = NT / G, NW = NT / 64;
-    __shared__ DetectWorld sh[WPB];
-    __shared__ int wtot[3][NW];
-    __shared__ int bbase[3];
+// One pass: kPhysThreads / 16 worlds starting at local index wfirst, 16 lanes each.  List space is
+// reserved with ONE atomic per list per pass (wave scans + workgroup scan).
+struct DetectLds {
+    DetectWorld sh[kPhysThreads / 16];
+    int wtot[3][kPhysWaves];
+    int bbase[3];
+};
+HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int par) {
+    constexpr int G = 16, NW = kPhysWaves;
+    DetectWorld *const sh = L.sh;
+    int (*const wtot)[NW] = L.wtot;
+    int *const bbase = L.bbase;
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
-    const int w = S.wbeg + blockIdx.x * WPB + grp;
+    const int w = S.wbeg + wfirst + grp;
     const int N = S.N;
-    const bool wok = w < S.wbeg + S.wcnt;
+    const bool wok = wfirst + grp < S.wcnt;
     DetectWorld &dw = sh[grp];
     int *cnt = S.counters + par * 4;
     int nwl = 0, npl = 0;
@@ -291,14 +306,23 @@ __global__ void __launch_bounds__(1024) k_detect(SimState S, int NS, int par) {
         S.gman[slot * N + w] = gword;
     }
 }
+HSD void phase_detect(const SimState &S, DetectLds &L, int NS, int par) {
+    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / 16) {
+        detect_pass(S, L, wfirst, NS, par);
+        __syncthreads();                  // the next pass reuses the LDS slots
+    }
+}
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_sat(SimState S, int par) {
-    __shared__ float clipmem[kClipWords];
+// kClipLanes lanes of every wave take an item (their clip polygons live in the wave's LDS slice).
+struct SatLds { float clipmem[kPhysWaves][kClipWords]; };
+HSD void phase_sat(const SimState &S, SatLds &L, int par) {
     const int N = S.N;
-    const int total = S.counters[par * 4 + 0];
-    const ClipBuf cb = {clipmem, (int)threadIdx.x};
-    for (int it = blockIdx.x * 64 + threadIdx.x; it < total; it += gridDim.x * 64) {
+    const int total = load_counter(&S.counters[par * 4 + 0]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= kClipLanes) return;
+    const ClipBuf cb = {L.clipmem[wave], lane};
+    for (int it = wave * kClipLanes + lane; it < total; it += kPhysWaves * kClipLanes) {
         const int item = S.satList[it];
         const int w = item >> 6, idx = item & 63;
         const bool isdd = idx < 32;
@@ -414,13 +438,13 @@ HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep
 // is still pending touches one of its bodies.  Disjoint pairs are solved in one round instead of
 // one after the other; the result is bit-identical to the sequential order.
 template <bool POS>
-__global__ void __launch_bounds__(64) k_dd(SimState S, int par) {
+HSD void phase_dd(const SimState &S, int par) {
     constexpr int GL = 8;
     const int N = S.N;
-    const int total = S.counters[par * 4 + 2];
+    const int total = load_counter(&S.counters[par * 4 + 2]);
     const int q = threadIdx.x % GL;
     const int gbit0 = (threadIdx.x & 63) / GL * GL;               // first lane of this group in the wave
-    for (int it = (blockIdx.x * 64 + threadIdx.x) / GL; ; it += gridDim.x * (64 / GL)) {
+    for (int it = threadIdx.x / GL; ; it += kPhysThreads / GL) {
         if (__ballot(it < total) == 0ull) break;                  // wave-uniform exit
         const bool live = it < total;
         const int w = live ? S.ddwList[it] : 0;
@@ -510,11 +534,8 @@ __global__ void __launch_bounds__(64) k_dd(SimState S, int par) {
 // the few lanes whose body has candidates; a packed per-body kernel was tried first and lost: those
 // kernels are bound by the latency of one lane's sequential solve, not by lane utilisation, so the
 // extra launch (drain + dispatch + reloading the body) cost more than the idle lanes do here.
-__global__ void __launch_bounds__(256) k_body_pos(SimState S, int NS) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+HSD void body_pos_item(const SimState &S, int slot, int w) {
     const int N = S.N;
-    if (t >= NS * S.wcnt) return;
-    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
     const int gword = S.gman[slot * N + w];
@@ -551,16 +572,19 @@ __global__ void __launch_bounds__(256) k_body_pos(SimState S, int NS) {
     derive_velocity(me);
     gbody_store_vel(S, w, slot, me);
 }
+HSD void phase_body_pos(const SimState &S, int NS) {
+    for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
+        const int slot = t / S.wcnt;
+        body_pos_item(S, slot, S.wbeg + (t - slot * S.wcnt));
+    }
+}
 
 // Velocity pass over a body's static contacts; with NEXT, also the start of the following substep
 // (parity par_next) for every body, so the body is integrated from registers instead of by a
 // separate launch.
 template <bool NEXT>
-__global__ void __launch_bounds__(256) k_body_vel(SimState S, int NS, int par_next) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+HSD void body_vel_item(const SimState &S, int t, int slot, int w, int par_next) {
     const int N = S.N;
-    if (t >= NS * S.wcnt) return;
-    const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
     if (NEXT) substep_begin(S, t, slot, w, par_next);
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0) return;
@@ -603,18 +627,26 @@ __global__ void __launch_bounds__(256) k_body_vel(SimState S, int NS, int par_ne
     if (NEXT) integrate_body(S, w, slot, meta, me.pos, me.rot, me.lin, me.ang);
     else gbody_store_vel(S, w, slot, me);
 }
+template <bool NEXT>
+HSD void phase_body_vel(const SimState &S, int NS, int par_next) {
+    for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
+        const int slot = t / S.wcnt;
+        body_vel_item<NEXT>(S, t, slot, S.wbeg + (t - slot * S.wcnt), par_next);
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // Before the substeps: movementSystem | instantMovementSystem (sim.cpp:202-254) and actionSystem
 // (:270-370).  One 16-lane group per world; the world is staged in LDS only when an agent
 // actually locks or grabs (needs ray casts), which scripts/benchmark.py never does.
-__global__ void __launch_bounds__(256) k_pre(SimState S) {
-    constexpr int G = 16, WPB = 256 / G;
-    __shared__ ActWorld sh[WPB];
+struct PreLds { ActWorld sh[kPhysThreads / 16]; };
+HSD void pre_pass(const SimState &S, PreLds &L, int wfirst) {
+    constexpr int G = 16;
+    ActWorld *const sh = L.sh;
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
-    const int w = S.wbeg + blockIdx.x * WPB + grp;
+    const int w = S.wbeg + wfirst + grp;
     const int N = S.N, A_ = S.A;
-    const bool wok = w < S.wbeg + S.wcnt;
+    const bool wok = wfirst + grp < S.wcnt;
     ActWorld &pw = sh[grp];
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     int teams = 0, step = 0;
@@ -640,7 +672,7 @@ __global__ void __launch_bounds__(256) k_pre(SimState S) {
             act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;   // sim.cpp:365-369
         }
     }
-    // any lock/grab request in this block?  (block-uniform decision so the barriers below are safe)
+    // any lock/grab request in this pass?  (workgroup-uniform decision so the barriers below are safe)
     const int any = __syncthreads_or(need_action ? 1 : 0);
     if (!any) return;
     if (wok) {
@@ -681,16 +713,24 @@ __global__ void __launch_bounds__(256) k_pre(SimState S) {
     }
 }
 
+HSD void phase_pre(const SimState &S, PreLds &L) {
+    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / 16) {
+        pre_pass(S, L, wfirst);
+        __syncthreads();
+    }
+}
+
 // After the substeps: agentZeroVelSystem (sim.cpp:258-268), rewardsVisSystem (:763-804),
 // outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893).
-__global__ void __launch_bounds__(256) k_post(SimState S) {
-    constexpr int G = 16, WPB = 256 / G;
-    __shared__ WorldGeom sh[WPB];
-    __shared__ int seen_flag[WPB];
+struct PostLds { WorldGeom sh[kPhysThreads / 16]; int seen_flag[kPhysThreads / 16]; };
+HSD void post_pass(const SimState &S, PostLds &L, int wfirst) {
+    constexpr int G = 16;
+    WorldGeom *const sh = L.sh;
+    int *const seen_flag = L.seen_flag;
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
-    const int w = S.wbeg + blockIdx.x * WPB + grp;
+    const int w = S.wbeg + wfirst + grp;
     const int N = S.N, A_ = S.A;
-    const bool wok = w < S.wbeg + S.wcnt;
+    const bool wok = wfirst + grp < S.wcnt;
     WorldGeom &g = sh[grp];
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     int teams = 0, step = 0, counts = 0;
@@ -770,6 +810,46 @@ __global__ void __launch_bounds__(256) k_post(SimState S) {
         S.runningScores[0 * N + w] = s0; S.runningScores[1 * N + w] = s1;
         S.hiderTeamReward[w] = hider_reward;
     }
+}
+
+HSD void phase_post(const SimState &S, PostLds &L) {
+    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / 16) {
+        post_pass(S, L, wfirst);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The phases share one LDS allocation (each uses it between two workgroup barriers).
+union PhysLds { DetectLds det; SatLds sat; PreLds pre; PostLds post; };
+
+__global__ void __launch_bounds__(kPhysThreads) k_physics(SimState S) {
+    __shared__ PhysLds lds;
+    // this workgroup's worlds, and its slices of the work lists / list-length counters
+    S.wbeg = blockIdx.x * kPhysWorlds;
+    S.wcnt = min(kPhysWorlds, S.N - S.wbeg);
+    S.satList += (size_t)S.wbeg * (kMaxDDCand + kMaxSCand);
+    S.ddwList += (size_t)S.wbeg * 2;
+    S.counters += blockIdx.x * 8;
+    const int NS = kAgentSlot0 + S.A;                 // body slots in use
+    phase_pre(S, lds.pre);
+    for (int sub = 0; sub < kNumSubsteps; ++sub) {
+        const int par = sub & 1;
+        if (sub == 0) { phase_integrate(S, NS, par); __syncthreads(); }
+        phase_detect(S, lds.det, NS, par);
+        phase_sat(S, lds.sat, par);
+        __syncthreads();
+        phase_dd<true>(S, par);
+        __syncthreads();
+        phase_body_pos(S, NS);
+        __syncthreads();
+        phase_dd<false>(S, par);
+        __syncthreads();
+        if (sub + 1 < kNumSubsteps) phase_body_vel<true>(S, NS, par ^ 1);
+        else phase_body_vel<false>(S, NS, 0);
+        __syncthreads();
+    }
+    phase_post(S, lds.post);
 }
 
 }  // namespace hs

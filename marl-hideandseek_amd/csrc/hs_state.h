@@ -20,7 +20,7 @@ struct SimState {
     RandKey initKey;       // rand::initKey(seed) (src/mgr.cpp:678)
     int minHiders, maxHiders, minSeekers, maxSeekers;
     int worldOffset;
-    int wbeg, wcnt;        // world range processed by a launch of the physics pipeline (a chunk of [0, N))
+    int wbeg, wcnt;        // world range owned by a workgroup of k_physics (set inside the kernel)
 
     // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
     float *bpos;           // [3][17][N]
@@ -62,8 +62,8 @@ struct SimState {
     int *ddPair, *scPair;  // [kMaxDDCand][N] a | b << 8 ; [kMaxSCand][N] body | static << 8
     int *wflags;           // [N]         1 = world has a grab joint
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
-    int *satList, *wallList, *ddwList;   // global work lists of one substep
-    int *counters;         // [2][4] list lengths (sat, wall, ddw), double-buffered by substep parity
+    int *satList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
+    int *counters;         // [workgroups][2][4] list lengths (sat, -, ddw), double-buffered by substep parity
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }
