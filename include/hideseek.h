@@ -190,6 +190,11 @@ int32_t hs_debug_dump_walls(hs_sim *sim, float *walls, int32_t *info);
 int32_t hs_set_profiling(hs_sim *sim, int32_t enabled);
 int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
 
+/* Development aid: per-phase wall-clock ticks (100 MHz) accumulated by every workgroup of the physics kernel,
+ * [groups][10] = pre, integrate, detect, sat, dd_pos, body_pos, dd_vel, body_vel, post, -; all zero unless the
+ * library was built with -DHS_PHASE_TIMING.  Returns the number of groups written (<= max_groups). */
+int32_t hs_debug_phase_ticks(hs_sim *sim, int64_t *out, int32_t max_groups);
+
 /* Profiling aid: one dword-per-lane coalesced copy of `bytes` bytes (read + write), used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */
 int32_t hs_debug_calibrate(int64_t bytes);

@@ -185,6 +185,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.wflags, N);
     HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.ddwList, 2 * N);
     HS_ALLOC(S.counters, 8 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
+    HS_ALLOC(S.phaseTicks, 10 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
 #undef HS_ALLOC
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
@@ -426,6 +427,16 @@ int32_t hs_jax_load_checkpoints(hs_sim *s, void *hip_stream, void **buffers) {
     if (rc == HS_OK) rc = launch_load_ckpts(s, strm);
     if (rc == HS_OK) rc = copy_out_observations(s, strm, &buffers);
     return rc;
+}
+
+// Development aid (HS_PHASE_TIMING builds): accumulated wall-clock ticks per phase per workgroup of k_physics.
+int32_t hs_debug_phase_ticks(hs_sim *s, int64_t *out, int32_t max_groups) {
+    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int nb = (s->S.N + hs::kPhysWorlds - 1) / hs::kPhysWorlds;
+    if (nb > max_groups) nb = max_groups;
+    HS_HIP(hipMemcpy(out, s->S.phaseTicks, (size_t)nb * 10 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return nb;
 }
 
 int32_t hs_debug_dump_bodies(hs_sim *s, float *bodies, int32_t *meta) {

@@ -32,8 +32,12 @@
 
 namespace hs {
 
-constexpr int kPhysThreads = 512;      // 8 waves per workgroup: 2 per SIMD, so the convex test keeps its ~220 VGPRs
-constexpr int kPhysWorlds = 64;        // worlds per workgroup (16 000 worlds -> 250 workgroups on 256 CUs)
+#ifndef HS_PHYS_THREADS
+#define HS_PHYS_THREADS 512
+#define HS_PHYS_WORLDS 64
+#endif
+constexpr int kPhysThreads = HS_PHYS_THREADS;      // 8 waves per workgroup: 2 per SIMD, so the convex test keeps its ~220 VGPRs
+constexpr int kPhysWorlds = HS_PHYS_WORLDS;        // worlds per workgroup (16 000 worlds -> 250 workgroups on 256 CUs)
 constexpr int kPhysWaves = kPhysThreads / 64;
 
 // List lengths are bumped with atomics (performed in L2) and read by other waves of the workgroup in
@@ -122,8 +126,24 @@ HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q 
         gst3(S.blin, S, slot, w, lin); gst3(S.bang, S, slot, w, ang);
     }
     V3 lo, hi;
-    hull_aabb(hull_ref_body(obj, pos, rot), &lo, &hi);
+    const HullRef hb = hull_ref_body(obj, pos, rot);
+    hull_aabb(hb, &lo, &hi);
     gst3(S.blo, S, slot, w, lo); gst3(S.bhi, S, slot, w, hi);
+    // ground plane (plane 0) manifold at the integrated pose; phase_detect adds the static-candidate range
+    int gword = 0;
+    if (meta_resp(meta) == RESP_DYNAMIC && S.numPlanes[w] >= 1) {
+        RawManifold raw;
+        const V3 pn = {S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
+        if (collide_hull_plane(hb, pn, S.planes[(3 * kMaxPlanes) * N + w], raw)) {
+            gword |= raw.np;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < raw.np) { gword |= raw.vidx[j] << (4 + 3 * j); S.goff[bidx(S, j, slot, w)] = dot(raw.pB[j], raw.n); }
+                S.glam[bidx(S, j, slot, w)] = 0.f;
+            }
+        }
+    }
+    S.gman[slot * N + w] = gword;
 }
 
 // Per-world bookkeeping at the start of substep `par`: clear the candidate counts, queue worlds with a
@@ -281,29 +301,12 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     if (push_ddw) S.ddwList[bbase[2] + wtot[2][wv] + incl[2] - 1] = w;
     __syncthreads();
     if (wok && l == 0) { S.ndd[w] = dw.ndd; S.nsc[w] = dw.nsc; }
-    // ---- ground plane (plane 0) manifold of the owned bodies
+    // ---- the static-candidate range of the owned bodies joins their ground-manifold word (phase_integrate)
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
         const int slot = l + jb * G;
-        if (!wok || slot >= NS) continue;
-        const int meta = dw.meta[slot];
-        if (meta == 0) continue;
-        int gword = asc[jb] > 0 ? (kGndHasWall | (bsc[jb] << kGndScBegShift) | (asc[jb] << kGndScCntShift)) : 0;
-        if (meta_resp(meta) == RESP_DYNAMIC && npl >= 1) {
-            const int obj = meta_obj(meta);
-            HullRef hb = hull_ref_body(obj, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w));
-            RawManifold raw;
-            const V3 pn = {S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
-            if (collide_hull_plane(hb, pn, S.planes[(3 * kMaxPlanes) * N + w], raw)) {
-                gword |= raw.np;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < raw.np) { gword |= raw.vidx[j] << (4 + 3 * j); S.goff[bidx(S, j, slot, w)] = dot(raw.pB[j], raw.n); }
-                    S.glam[bidx(S, j, slot, w)] = 0.f;
-                }
-            }
-        }
-        S.gman[slot * N + w] = gword;
+        if (!wok || slot >= NS || asc[jb] <= 0) continue;
+        S.gman[slot * N + w] |= kGndHasWall | (bsc[jb] << kGndScBegShift) | (asc[jb] << kGndScCntShift);
     }
 }
 HSD void phase_detect(const SimState &S, DetectLds &L, int NS, int par) {
@@ -823,7 +826,7 @@ HSD void phase_post(const SimState &S, PostLds &L) {
 // The phases share one LDS allocation (each uses it between two workgroup barriers).
 union PhysLds { DetectLds det; SatLds sat; PreLds pre; PostLds post; };
 
-__global__ void __launch_bounds__(kPhysThreads) k_physics(SimState S) {
+__global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     __shared__ PhysLds lds;
     // this workgroup's worlds, and its slices of the work lists / list-length counters
     S.wbeg = blockIdx.x * kPhysWorlds;
@@ -832,24 +835,44 @@ __global__ void __launch_bounds__(kPhysThreads) k_physics(SimState S) {
     S.ddwList += (size_t)S.wbeg * 2;
     S.counters += blockIdx.x * 8;
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
+#ifdef HS_PHASE_TIMING
+    // development aid: wall-clock ticks (100 MHz) per phase of every workgroup -> S.phaseTicks[workgroup][10]
+    long long tk = wall_clock64(); long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HS_TICK(i) { __syncthreads(); const long long now_ = wall_clock64(); acc[i] += now_ - tk; tk = now_; }
+#else
+#define HS_TICK(i)
+#endif
     phase_pre(S, lds.pre);
+    HS_TICK(0)
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const int par = sub & 1;
         if (sub == 0) { phase_integrate(S, NS, par); __syncthreads(); }
+        HS_TICK(1)
         phase_detect(S, lds.det, NS, par);
+        HS_TICK(2)
         phase_sat(S, lds.sat, par);
         __syncthreads();
+        HS_TICK(3)
         phase_dd<true>(S, par);
         __syncthreads();
+        HS_TICK(4)
         phase_body_pos(S, NS);
         __syncthreads();
+        HS_TICK(5)
         phase_dd<false>(S, par);
         __syncthreads();
+        HS_TICK(6)
         if (sub + 1 < kNumSubsteps) phase_body_vel<true>(S, NS, par ^ 1);
         else phase_body_vel<false>(S, NS, 0);
         __syncthreads();
+        HS_TICK(7)
     }
     phase_post(S, lds.post);
+    HS_TICK(8)
+#ifdef HS_PHASE_TIMING
+    if (threadIdx.x == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[blockIdx.x * 10 + i] += acc[i];
+#endif
+#undef HS_TICK
 }
 
 }  // namespace hs

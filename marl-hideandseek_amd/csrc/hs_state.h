@@ -63,6 +63,7 @@ struct SimState {
     int *wflags;           // [N]         1 = world has a grab joint
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
     int *satList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
+    long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
     int *counters;         // [workgroups][2][4] list lengths (sat, -, ddw), double-buffered by substep parity
 };
 
