@@ -14,9 +14,8 @@
 // the work lists (wavefront scan + one atomic per list) and processed one lane (or 8) per item.
 //
 // Substep s:
-//   integrate        slot-major   (substep 0; later ones happen at the end of body_vel)
-//   detect           16 lanes/world  all-pairs AABB candidates -> per-world lists + work lists;
-//                                 ground-plane manifold of every body
+//   integrate        slot-major   (substep 0; later ones happen at the end of body_vel); ground-plane manifold
+//   detect           8 lanes/world   all-pairs AABB candidates -> per-world lists + work lists
 //   sat              per pair     exact convex test -> manifold workspace
 //   dd<pos>          8 lanes/world*  joints, then body-body manifolds in (i<j) order   (*worlds that have any)
 //   body_pos         slot-major   ground manifold, the body's wall / extra-plane manifolds; velocity derivation
@@ -184,15 +183,16 @@ struct DetectWorld {
     int ndd, nsc;
 };
 
-// One pass: kPhysThreads / 16 worlds starting at local index wfirst, 16 lanes each.  List space is
+// One pass: kPhysThreads / kDetectLanes worlds starting at local index wfirst.  List space is
 // reserved with ONE atomic per list per pass (wave scans + workgroup scan).
+constexpr int kDetectLanes = 8;        // lanes per world in phase_detect: lane l owns body slots l, l+8, l+16
 struct DetectLds {
-    DetectWorld sh[kPhysThreads / 16];
+    DetectWorld sh[kPhysThreads / kDetectLanes];
     int wtot[3][kPhysWaves];
     int bbase[3];
 };
 HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int par) {
-    constexpr int G = 16, NW = kPhysWaves;
+    constexpr int G = kDetectLanes, JB = (kNumDSlots + G - 1) / G, NW = kPhysWaves;
     DetectWorld *const sh = L.sh;
     int (*const wtot)[NW] = L.wtot;
     int *const bbase = L.bbase;
@@ -220,12 +220,12 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
         if (l == 0) { dw.ndd = 0; dw.nsc = 0; }
     }
     __syncthreads();
-    // a lane owns slot l (and slot 16 as lane 0's second body when 6 agents are configured)
+    // lane l owns body slots l, l + 8 (and lane 0 slot 16 when 6 agents are configured)
     int tot_items = 0;
-    unsigned dd_mask[2] = {0, 0}; unsigned long long s_mask[2] = {0ull, 0ull};
-    int bdd[2] = {0, 0}, bsc[2] = {0, 0}, add[2] = {0, 0}, asc[2] = {0, 0};
+    unsigned dd_mask[JB] = {}; unsigned long long s_mask[JB] = {};
+    int bdd[JB] = {}, bsc[JB] = {}, add[JB] = {}, asc[JB] = {};
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
         if (!wok || slot >= NS) continue;
         const int meta = dw.meta[slot];
@@ -257,7 +257,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     const int lane = tid & 63, wv = tid >> 6;
     bool push_ddw = false;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) push_ddw |= add[jb] > 0 && bdd[jb] == 0;
+    for (int jb = 0; jb < JB; ++jb) push_ddw |= add[jb] > 0 && bdd[jb] == 0;
     push_ddw = push_ddw && wok && S.wflags[w] == 0;
     int mine[3] = {tot_items, 0, push_ddw ? 1 : 0};
     int incl[3];
@@ -278,7 +278,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     __syncthreads();
     int gbase = bbase[0] + wtot[0][wv] + incl[0] - mine[0];
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
         unsigned mm = dd_mask[jb]; int i = 0;
         while (mm && i < add[jb]) {
@@ -303,14 +303,14 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     if (wok && l == 0) { S.ndd[w] = dw.ndd; S.nsc[w] = dw.nsc; }
     // ---- the static-candidate range of the owned bodies joins their ground-manifold word (phase_integrate)
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
         if (!wok || slot >= NS || asc[jb] <= 0) continue;
         S.gman[slot * N + w] |= kGndHasWall | (bsc[jb] << kGndScBegShift) | (asc[jb] << kGndScCntShift);
     }
 }
 HSD void phase_detect(const SimState &S, DetectLds &L, int NS, int par) {
-    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / 16) {
+    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / kDetectLanes) {
         detect_pass(S, L, wfirst, NS, par);
         __syncthreads();                  // the next pass reuses the LDS slots
     }
