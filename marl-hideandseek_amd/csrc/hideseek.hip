@@ -40,7 +40,7 @@ struct hs_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[3] = {0.f, 0.f, 0.f};
     bool initialised = false;
-    bool use_graph = true;                 // env HS_GRAPH=0 disables
+    bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower now that a step is three launches)
     hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
@@ -93,9 +93,10 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     return HS_OK;
 }
 
-// The step as three HIP graphs (physics pipeline, reset, observe): captured once on a private stream (the
-// legacy stream cannot be captured) and replayed on the caller's stream.  ~40 host launches per step become
-// three; the profiling events stay ordinary stream events between the graph launches.
+// Optional (HS_GRAPH=1): the step as three HIP graphs (physics, reset, observe), captured once on a private
+// stream (the legacy stream cannot be captured) and replayed on the caller's stream; the profiling events stay
+// ordinary stream events between the graph launches.  It paid off while physics was ~40 launches per step;
+// with the persistent physics kernel a step is three launches and the direct launches are faster.
 int launch_step(hs_sim *s, hipStream_t strm, bool first) {
     if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling);
     if (!s->graph_exec[0]) {
@@ -180,10 +181,10 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
     HS_ALLOC(S.bppos, 3 * D * N); HS_ALLOC(S.bprot, 4 * D * N); HS_ALLOC(S.blo, 3 * D * N); HS_ALLOC(S.bhi, 3 * D * N);
-    HS_ALLOC(S.gman, D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
+    HS_ALLOC(S.gman, 2 * D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
     HS_ALLOC(S.ndd, N); HS_ALLOC(S.nsc, N); HS_ALLOC(S.ddPair, hs::kMaxDDCand * N); HS_ALLOC(S.scPair, hs::kMaxSCand * N);
     HS_ALLOC(S.wflags, N);
-    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.ddwList, 2 * N);
+    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.ddwList, 2 * N);
     HS_ALLOC(S.counters, 8 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
     HS_ALLOC(S.phaseTicks, 10 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
 #undef HS_ALLOC

@@ -94,11 +94,14 @@ HSD void wave_push(int *list, int *counter, int value, bool pred) {
 // static candidate count << 21 | hasStaticCandidates << 30
 constexpr int kGndHasWall = 1 << 30;
 constexpr int kGndScBegShift = 16, kGndScCntShift = 21;
+// The word is double-buffered by substep parity: the end of phase_body_vel writes the next substep's word while
+// other lanes of the phase still read this substep's.
+HSD int gman_idx(const SimState &S, int par, int slot, int w) { return (par * kNumDSlots + slot) * S.N + w; }
 
 // ------------------------------------------------------------------------------------------
 // Start of a substep for one body: remember the pose, semi-implicit Euler step (gravity, agent force
 // and torque, gyroscopic term), refresh the hull AABB.
-HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q rot, V3 lin, V3 ang) {
+HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q rot, V3 lin, V3 ang, int par) {
     const int N = S.N;
     const int obj = meta_obj(meta);
     gst3(S.bppos, S, slot, w, pos); gst4(S.bprot, S, slot, w, rot);
@@ -142,14 +145,13 @@ HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q 
             }
         }
     }
-    S.gman[slot * N + w] = gword;
+    S.gman[gman_idx(S, par, slot, w)] = gword;
 }
 
 // Per-world bookkeeping at the start of substep `par`: clear the candidate counts, queue worlds with a
-// grab joint for k_dd, and (thread 0) clear the list lengths of the following substep.
-HSD void substep_begin(const SimState &S, int t, int slot, int w, int par) {
+// grab joint for phase_dd.  (The list lengths of a parity are cleared by phase_detect of the other one.)
+HSD void substep_begin(const SimState &S, int slot, int w, int par) {
     const int N = S.N;
-    if (t == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }
     if (slot == 0) {
         S.ndd[w] = 0; S.nsc[w] = 0;
         bool grab = false;
@@ -164,12 +166,12 @@ HSD void phase_integrate(const SimState &S, int NS, int par) {
     const int N = S.N;
     for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
         const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
-        substep_begin(S, t, slot, w, par);
+        substep_begin(S, slot, w, par);
         const int meta = S.bmeta[slot * N + w];
         if (meta == 0) continue;
         V3 lin = {0.f, 0.f, 0.f}, ang = {0.f, 0.f, 0.f};
         if (meta_resp(meta) == RESP_DYNAMIC) { lin = gld3(S.blin, S, slot, w); ang = gld3(S.bang, S, slot, w); }
-        integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang);
+        integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang, par);
     }
 }
 
@@ -202,6 +204,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     const bool wok = wfirst + grp < S.wcnt;
     DetectWorld &dw = sh[grp];
     int *cnt = S.counters + par * 4;
+    if (tid == 0 && wfirst == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }
     int nwl = 0, npl = 0;
     if (wok) {
         nwl = S.numWalls[w]; npl = S.numPlanes[w];
@@ -256,10 +259,11 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     // ---- reserve space in the three global work lists: wave scans, block scan, one atomic per list
     const int lane = tid & 63, wv = tid >> 6;
     bool push_ddw = false;
+    int n_wall = 0;
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) push_ddw |= add[jb] > 0 && bdd[jb] == 0;
+    for (int jb = 0; jb < JB; ++jb) { push_ddw |= add[jb] > 0 && bdd[jb] == 0; n_wall += asc[jb] > 0 ? 1 : 0; }
     push_ddw = push_ddw && wok && S.wflags[w] == 0;
-    int mine[3] = {tot_items, 0, push_ddw ? 1 : 0};
+    int mine[3] = {tot_items, n_wall, push_ddw ? 1 : 0};
     int incl[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -277,6 +281,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     }
     __syncthreads();
     int gbase = bbase[0] + wtot[0][wv] + incl[0] - mine[0];
+    int wbase2 = bbase[1] + wtot[1][wv] + incl[1] - mine[1];
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
@@ -297,6 +302,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
             S.satList[gbase++] = (w << 6) | 32 | (bsc[jb] + i);
             ++i;
         }
+        if (asc[jb] > 0) S.wallList[wbase2++] = (w << 5) | slot;      // bodies with static candidates: own work items
     }
     if (push_ddw) S.ddwList[bbase[2] + wtot[2][wv] + incl[2] - 1] = w;
     __syncthreads();
@@ -306,7 +312,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
         if (!wok || slot >= NS || asc[jb] <= 0) continue;
-        S.gman[slot * N + w] |= kGndHasWall | (bsc[jb] << kGndScBegShift) | (asc[jb] << kGndScCntShift);
+        S.gman[gman_idx(S, par, slot, w)] |= kGndHasWall | (bsc[jb] << kGndScBegShift) | (asc[jb] << kGndScCntShift);
     }
 }
 HSD void phase_detect(const SimState &S, DetectLds &L, int NS, int par) {
@@ -537,13 +543,15 @@ HSD void phase_dd(const SimState &S, int par) {
 // the few lanes whose body has candidates; a packed per-body kernel was tried first and lost: those
 // kernels are bound by the latency of one lane's sequential solve, not by lane utilisation, so the
 // extra launch (drain + dispatch + reloading the body) cost more than the idle lanes do here.
-HSD void body_pos_item(const SimState &S, int slot, int w) {
+template <bool WALLED>
+HSD void body_pos_item(const SimState &S, int slot, int w, int par) {
     const int N = S.N;
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0 || meta_resp(meta) != RESP_DYNAMIC) return;
-    const int gword = S.gman[slot * N + w];
+    const int gword = S.gman[gman_idx(S, par, slot, w)];
     const int np = gword & 7;
     const bool has_wall = (gword & kGndHasWall) != 0;
+    if (has_wall != WALLED) return;       // bodies with static candidates are separate work items
     const int obj = meta_obj(meta);
     BodyS me, none;
     gbody_load(S, w, slot, me);
@@ -575,31 +583,49 @@ HSD void body_pos_item(const SimState &S, int slot, int w) {
     derive_velocity(me);
     gbody_store_vel(S, w, slot, me);
 }
-HSD void phase_body_pos(const SimState &S, int NS) {
-    for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
+// The few bodies with wall / extra-plane candidates take 2-3x longer than the others, so they are not
+// left inside the slot-major waves (where 63 lanes would wait for one): the first waves take them packed
+// from the wall-body list while the other waves start on the slot-major chunks, handed out 64 items at a
+// time from an LDS counter; whoever finishes first takes more chunks.
+HSD int next_chunk(int *ctr) {
+    int c = 0;
+    if ((threadIdx.x & 63) == 0) c = atomicAdd(ctr, 1);
+    return __shfl(c, 0);
+}
+HSD void phase_body_pos(const SimState &S, int NS, int par, int *chunk_ctr) {
+    const int nwall = load_counter(&S.counters[par * 4 + 1]);
+    for (int it = threadIdx.x; it < nwall; it += kPhysThreads) {
+        const int item = S.wallList[it];
+        body_pos_item<true>(S, item & 31, item >> 5, par);
+    }
+    const int total = NS * S.wcnt;
+    for (int c = next_chunk(chunk_ctr); c * 64 < total; c = next_chunk(chunk_ctr)) {
+        const int t = c * 64 + (threadIdx.x & 63);
+        if (t >= total) continue;
         const int slot = t / S.wcnt;
-        body_pos_item(S, slot, S.wbeg + (t - slot * S.wcnt));
+        body_pos_item<false>(S, slot, S.wbeg + (t - slot * S.wcnt), par);
     }
 }
 
 // Velocity pass over a body's static contacts; with NEXT, also the start of the following substep
 // (parity par_next) for every body, so the body is integrated from registers instead of by a
 // separate launch.
-template <bool NEXT>
-HSD void body_vel_item(const SimState &S, int t, int slot, int w, int par_next) {
+template <bool NEXT, bool WALLED>
+HSD void body_vel_item(const SimState &S, int slot, int w, int par, int par_next) {
     const int N = S.N;
-    if (NEXT) substep_begin(S, t, slot, w, par_next);
+    if (NEXT && !WALLED) substep_begin(S, slot, w, par_next);
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0) return;
     if (meta_resp(meta) != RESP_DYNAMIC) {
-        if (NEXT) integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), V3{0.f, 0.f, 0.f}, V3{0.f, 0.f, 0.f});
+        if (NEXT) integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), V3{0.f, 0.f, 0.f}, V3{0.f, 0.f, 0.f}, par_next);
         return;
     }
-    const int gword = S.gman[slot * N + w];
+    const int gword = S.gman[gman_idx(S, par, slot, w)];
     const int np = gword & 7;
     const bool has_wall = (gword & kGndHasWall) != 0;
+    if (has_wall != WALLED) return;       // bodies with static candidates are separate work items
     if (np == 0 && !has_wall) {
-        if (NEXT) integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), gld3(S.blin, S, slot, w), gld3(S.bang, S, slot, w));
+        if (NEXT) integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), gld3(S.blin, S, slot, w), gld3(S.bang, S, slot, w), par_next);
         return;
     }
     const int obj = meta_obj(meta);
@@ -627,14 +653,22 @@ HSD void body_vel_item(const SimState &S, int t, int slot, int w, int par_next) 
                 if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
         }
     }
-    if (NEXT) integrate_body(S, w, slot, meta, me.pos, me.rot, me.lin, me.ang);
+    if (NEXT) integrate_body(S, w, slot, meta, me.pos, me.rot, me.lin, me.ang, par_next);
     else gbody_store_vel(S, w, slot, me);
 }
 template <bool NEXT>
-HSD void phase_body_vel(const SimState &S, int NS, int par_next) {
-    for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
+HSD void phase_body_vel(const SimState &S, int NS, int par, int par_next, int *chunk_ctr) {
+    const int nwall = load_counter(&S.counters[par * 4 + 1]);
+    for (int it = threadIdx.x; it < nwall; it += kPhysThreads) {
+        const int item = S.wallList[it];
+        body_vel_item<NEXT, true>(S, item & 31, item >> 5, par, par_next);
+    }
+    const int total = NS * S.wcnt;
+    for (int c = next_chunk(chunk_ctr); c * 64 < total; c = next_chunk(chunk_ctr)) {
+        const int t = c * 64 + (threadIdx.x & 63);
+        if (t >= total) continue;
         const int slot = t / S.wcnt;
-        body_vel_item<NEXT>(S, t, slot, S.wbeg + (t - slot * S.wcnt), par_next);
+        body_vel_item<NEXT, false>(S, slot, S.wbeg + (t - slot * S.wcnt), par, par_next);
     }
 }
 
@@ -828,11 +862,13 @@ union PhysLds { DetectLds det; SatLds sat; PreLds pre; PostLds post; };
 
 __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     __shared__ PhysLds lds;
+    __shared__ int chunk_ctr[2];           // next slot-major chunk of phase_body_pos / phase_body_vel
     // this workgroup's worlds, and its slices of the work lists / list-length counters
     S.wbeg = blockIdx.x * kPhysWorlds;
     S.wcnt = min(kPhysWorlds, S.N - S.wbeg);
     S.satList += (size_t)S.wbeg * (kMaxDDCand + kMaxSCand);
     S.ddwList += (size_t)S.wbeg * 2;
+    S.wallList += (size_t)S.wbeg * kNumDSlots;
     S.counters += blockIdx.x * 8;
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
 #ifdef HS_PHASE_TIMING
@@ -848,6 +884,7 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
         const int par = sub & 1;
         if (sub == 0) { phase_integrate(S, NS, par); __syncthreads(); }
         HS_TICK(1)
+        if (threadIdx.x == 0) { chunk_ctr[0] = 0; chunk_ctr[1] = 0; }
         phase_detect(S, lds.det, NS, par);
         HS_TICK(2)
         phase_sat(S, lds.sat, par);
@@ -856,14 +893,14 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
         phase_dd<true>(S, par);
         __syncthreads();
         HS_TICK(4)
-        phase_body_pos(S, NS);
+        phase_body_pos(S, NS, par, &chunk_ctr[0]);
         __syncthreads();
         HS_TICK(5)
         phase_dd<false>(S, par);
         __syncthreads();
         HS_TICK(6)
-        if (sub + 1 < kNumSubsteps) phase_body_vel<true>(S, NS, par ^ 1);
-        else phase_body_vel<false>(S, NS, 0);
+        if (sub + 1 < kNumSubsteps) phase_body_vel<true>(S, NS, par, par ^ 1, &chunk_ctr[1]);
+        else phase_body_vel<false>(S, NS, par, 0, &chunk_ctr[1]);
         __syncthreads();
         HS_TICK(7)
     }

@@ -56,15 +56,15 @@ struct SimState {
     // --- substep scratch of the physics pipeline (hs_k_pipeline.h), all SoA across worlds
     float *bppos, *bprot;  // [3][17][N], [4][17][N]  pose at the start of the substep
     float *blo, *bhi;      // [3][17][N]  hull AABBs
-    int *gman;             // [17][N]     ground manifold: np | vertex ids << 4 | has-static-candidates << 30
+    int *gman;             // [2][17][N] (double-buffered by substep parity)     ground manifold: np | vertex ids << 4 | has-static-candidates << 30
     float *goff, *glam;    // [4][17][N]  ground manifold plane offsets / accumulated multipliers
     int *ndd, *nsc;        // [N]         candidate counts
     int *ddPair, *scPair;  // [kMaxDDCand][N] a | b << 8 ; [kMaxSCand][N] body | static << 8
     int *wflags;           // [N]         1 = world has a grab joint
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
-    int *satList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
+    int *satList, *wallList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
     long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
-    int *counters;         // [workgroups][2][4] list lengths (sat, -, ddw), double-buffered by substep parity
+    int *counters;         // [workgroups][2][4] list lengths (sat, wall bodies, ddw), double-buffered by substep parity
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }

@@ -1,0 +1,24 @@
+import os, sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, "marl-hideandseek_amd")
+import gpu_hideseek
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
+sim = gpu_hideseek.HideAndSeekSimulator(exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=N, sim_flags=0, rand_seed=0,
+    min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+act = sim.action_tensor().to_torch()
+sim.init()
+steps = 240
+for i in range(steps):
+    act[:, :2] = torch.randint(-5, 5, (N * 4, 2), dtype=torch.int32, device="cuda")
+    sim.step()
+nb = (N + 63) // 64
+out = np.zeros((nb, 10), np.int64)
+L = sim._L
+L.hs_debug_phase_ticks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+n = L.hs_debug_phase_ticks(sim._h, out.ctypes.data, nb)
+us = out[:n] / 100.0 / steps     # 100 MHz ticks -> us per step
+names = ["pre", "integrate", "detect", "sat", "dd_pos", "body_pos", "dd_vel", "body_vel", "post"]
+print("phase      mean_us  min_us  max_us   (per step, over %d workgroups)" % n)
+for i, nm in enumerate(names):
+    print(f"{nm:10s} {us[:, i].mean():7.1f} {us[:, i].min():7.1f} {us[:, i].max():7.1f}")
+tot = us.sum(axis=1)
+print(f"total      {tot.mean():7.1f} {tot.min():7.1f} {tot.max():7.1f}")
