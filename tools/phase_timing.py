@@ -1,5 +1,11 @@
+"""Per-phase time of the persistent physics kernel (development aid).
+
+Needs a library built with -DHS_PHASE_TIMING (pass it through HS_LIB_PATH):
+  hipcc <build.py flags> -DHS_PHASE_TIMING -o variants/lib_timing.so marl-hideandseek_amd/csrc/hideseek.hip
+  HS_LIB_PATH=$PWD/variants/lib_timing.so python tools/phase_timing.py 16000
+"""
 import os, sys, ctypes as C, numpy as np, torch
-sys.path.insert(0, "marl-hideandseek_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "marl-hideandseek_amd"))
 import gpu_hideseek
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
 sim = gpu_hideseek.HideAndSeekSimulator(exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=N, sim_flags=0, rand_seed=0,
