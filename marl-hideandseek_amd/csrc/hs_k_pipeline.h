@@ -190,8 +190,8 @@ struct DetectWorld {
 constexpr int kDetectLanes = 8;        // lanes per world in phase_detect: lane l owns body slots l, l+8, l+16
 struct DetectLds {
     DetectWorld sh[kPhysThreads / kDetectLanes];
-    int wtot[3][kPhysWaves];
-    int bbase[3];
+    int wtot[4][kPhysWaves];
+    int bbase[4];
 };
 HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int par) {
     constexpr int G = kDetectLanes, JB = (kNumDSlots + G - 1) / G, NW = kPhysWaves;
@@ -204,7 +204,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     const bool wok = wfirst + grp < S.wcnt;
     DetectWorld &dw = sh[grp];
     int *cnt = S.counters + par * 4;
-    if (tid == 0 && wfirst == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; }
+    if (tid == 0 && wfirst == 0) { int *c = S.counters + ((par ^ 1) * 4); c[0] = 0; c[1] = 0; c[2] = 0; c[3] = 0; }
     int nwl = 0, npl = 0;
     if (wok) {
         nwl = S.numWalls[w]; npl = S.numPlanes[w];
@@ -256,17 +256,25 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
     }
-    // ---- reserve space in the three global work lists: wave scans, block scan, one atomic per list
+    // ---- reserve space in the work lists: wave scans, workgroup scan, one atomic per list.
+    // Convex-test items that involve a ramp (wedge hull) are kept apart from the box-only ones — they go
+    // to the far end of the workgroup's list slice — so that most waves of phase_sat run the box code only.
     const int lane = tid & 63, wv = tid >> 6;
     bool push_ddw = false;
-    int n_wall = 0;
+    int n_wall = 0, n_wedge = 0;
 #pragma unroll
-    for (int jb = 0; jb < JB; ++jb) { push_ddw |= add[jb] > 0 && bdd[jb] == 0; n_wall += asc[jb] > 0 ? 1 : 0; }
+    for (int jb = 0; jb < JB; ++jb) {
+        push_ddw |= add[jb] > 0 && bdd[jb] == 0; n_wall += asc[jb] > 0 ? 1 : 0;
+        const int slot = l + jb * G;
+        const bool ramp = slot >= kRampSlot0 && slot < kRampSlot0 + kMaxRamps;
+        if (ramp) n_wedge += add[jb] + asc[jb];
+        else { unsigned mm = dd_mask[jb]; for (int i = 0; mm && i < add[jb]; ++i) { const int j = __ffs(mm) - 1; mm &= mm - 1; n_wedge += (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps) ? 1 : 0; } }
+    }
     push_ddw = push_ddw && wok && S.wflags[w] == 0;
-    int mine[3] = {tot_items, n_wall, push_ddw ? 1 : 0};
-    int incl[3];
+    int mine[4] = {tot_items - n_wedge, n_wall, push_ddw ? 1 : 0, n_wedge};
+    int incl[4];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 4; ++q) {
         int x = mine[q];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
@@ -274,7 +282,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
         if (lane == 63) wtot[q][wv] = x;
     }
     __syncthreads();
-    if (tid < 3) {
+    if (tid < 4) {
         int tot = 0;
         for (int k = 0; k < NW; ++k) { const int c = wtot[tid][k]; wtot[tid][k] = tot; tot += c; }
         bbase[tid] = tot > 0 ? atomicAdd(&cnt[tid], tot) : 0;
@@ -282,14 +290,17 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
     __syncthreads();
     int gbase = bbase[0] + wtot[0][wv] + incl[0] - mine[0];
     int wbase2 = bbase[1] + wtot[1][wv] + incl[1] - mine[1];
+    int gback = S.wcnt * (kMaxDDCand + kMaxSCand) - 1 - (bbase[3] + wtot[3][wv] + incl[3] - mine[3]);
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
+        const bool ramp = slot >= kRampSlot0 && slot < kRampSlot0 + kMaxRamps;
         unsigned mm = dd_mask[jb]; int i = 0;
         while (mm && i < add[jb]) {
             const int j = __ffs(mm) - 1; mm &= mm - 1;
             S.ddPair[(bdd[jb] + i) * N + w] = slot | (j << 8);
-            S.satList[gbase++] = (w << 6) | (bdd[jb] + i);
+            const int item = (w << 6) | (bdd[jb] + i);
+            if (ramp || (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps)) S.satList[gback--] = item; else S.satList[gbase++] = item;
             ++i;
         }
         // oracle order inside a body: extra planes first, then walls by index; the body's candidates
@@ -299,7 +310,8 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
             const int bit = __ffsll((long long)sm) - 1; sm &= sm - 1;
             const int k = bit < kMaxPlanes ? kMaxWalls + bit : bit - kMaxPlanes;
             S.scPair[(bsc[jb] + i) * N + w] = slot | (k << 8);
-            S.satList[gbase++] = (w << 6) | 32 | (bsc[jb] + i);
+            const int item = (w << 6) | 32 | (bsc[jb] + i);
+            if (ramp) S.satList[gback--] = item; else S.satList[gbase++] = item;
             ++i;
         }
         if (asc[jb] > 0) S.wallList[wbase2++] = (w << 5) | slot;      // bodies with static candidates: own work items
@@ -327,12 +339,16 @@ HSD void phase_detect(const SimState &S, DetectLds &L, int NS, int par) {
 struct SatLds { float clipmem[kPhysWaves][kClipWords]; };
 HSD void phase_sat(const SimState &S, SatLds &L, int par) {
     const int N = S.N;
-    const int total = load_counter(&S.counters[par * 4 + 0]);
+    // box-only items from the front of the list, then (starting at a fresh wave) the ramp items from its far end
+    const int nbox = load_counter(&S.counters[par * 4 + 0]), nwedge = load_counter(&S.counters[par * 4 + 3]);
+    const int wedge0 = (nbox + kClipLanes - 1) / kClipLanes * kClipLanes;
+    const int total = wedge0 + nwedge, cap = S.wcnt * (kMaxDDCand + kMaxSCand);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane >= kClipLanes) return;
     const ClipBuf cb = {L.clipmem[wave], lane};
     for (int it = wave * kClipLanes + lane; it < total; it += kPhysWaves * kClipLanes) {
-        const int item = S.satList[it];
+        if (it >= nbox && it < wedge0) continue;
+        const int item = it < nbox ? S.satList[it] : S.satList[cap - 1 - (it - wedge0)];
         const int w = item >> 6, idx = item & 63;
         const bool isdd = idx < 32;
         const int kk = idx & 31;
