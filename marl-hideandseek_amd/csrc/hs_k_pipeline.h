@@ -775,9 +775,10 @@ HSD void phase_pre(const SimState &S, PreLds &L) {
 
 // After the substeps: agentZeroVelSystem (sim.cpp:258-268), rewardsVisSystem (:763-804),
 // outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893).
-struct PostLds { WorldGeom sh[kPhysThreads / 16]; int seen_flag[kPhysThreads / 16]; };
+constexpr int kPostLanes = 8;           // lanes per world in phase_post: the workgroup's 64 worlds in one pass
+struct PostLds { WorldGeom sh[kPhysThreads / kPostLanes]; int seen_flag[kPhysThreads / kPostLanes]; };
 HSD void post_pass(const SimState &S, PostLds &L, int wfirst) {
-    constexpr int G = 16;
+    constexpr int G = kPostLanes;
     WorldGeom *const sh = L.sh;
     int *const seen_flag = L.seen_flag;
     const int tid = threadIdx.x, grp = tid / G, l = tid % G;
@@ -814,8 +815,8 @@ HSD void post_pass(const SimState &S, PostLds &L, int wfirst) {
         }
     }
     __syncthreads();
-    if (wok && l < 9) {
-        const int si = l / 3, hi_ = l % 3;
+    for (int pr = l; wok && pr < 9; pr += G) {      // (seeker, hider) pairs
+        const int si = pr / 3, hi_ = pr % 3;
         if (si < cnt_seekers(counts) && hi_ < cnt_hiders(counts)) {
             const int ss = kAgentSlot0 + team_seeker(teams, si), hs_ = kAgentSlot0 + team_hider(teams, hi_);
             const V3 spos = geom_pos(g, ss);
@@ -866,7 +867,7 @@ HSD void post_pass(const SimState &S, PostLds &L, int wfirst) {
 }
 
 HSD void phase_post(const SimState &S, PostLds &L) {
-    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / 16) {
+    for (int wfirst = 0; wfirst < S.wcnt; wfirst += kPhysThreads / kPostLanes) {
         post_pass(S, L, wfirst);
         __syncthreads();
     }
