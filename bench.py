@@ -139,12 +139,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # Roofline position of the dominant stage.  The physics pipeline is 38 launches (k_pre, 4 x 9 substep
-    # kernels, k_post) timed as one region; k_reset and k_observe are single kernels.  Durations are HIP
-    # events on the launch stream (hs_set_profiling); profiles/ holds the rocprofv3 --kernel-trace --stats
-    # summary of this command: the per-kernel averages there sum to the same region times.
-    names = {"physics": "physics pipeline (k_pre + 4x{k_integrate,k_detect,k_sat,k_dd_pos,k_ground_pos,k_walls_pos,"
-                        "k_dd_vel,k_ground_vel,k_walls_vel} + k_post)", "reset": "k_reset", "observe": "k_observe"}
+    # Roofline position of the dominant kernel.  A step is three kernels: k_physics (persistent: movement /
+    # actions, 4 XPBD substeps, rewards), k_reset, k_observe.  Durations are HIP events on the launch stream
+    # (hs_set_profiling); profiles/ holds the rocprofv3 --kernel-trace --stats summary of this command, whose
+    # per-kernel averages agree with them.
+    names = {"physics": "k_physics", "reset": "k_reset", "observe": "k_observe"}
     per_stage = {}
     for n in kms:
         avg_ms = kms[n] / max(args.steps, 1)

@@ -50,8 +50,7 @@ def main():
         wn, wtot = write.get(name, [n, 0.0])
         per[s] = {"launches": n, "fetch_KiB_per_launch_raw": tot / n, "write_KiB_per_launch": wtot / max(wn, 1),
                   "hbm_bytes_per_launch": tot / n * 1024.0 * fetch_factor + wtot / max(wn, 1) * 1024.0 * write_factor}
-    sub = ["k_integrate", "k_detect", "k_sat", "k_dd_pos", "k_ground_pos", "k_walls_pos", "k_dd_vel", "k_ground_vel", "k_walls_vel"]
-    phys = sum(4 * per[k]["hbm_bytes_per_launch"] for k in sub if k in per) + sum(per[k]["hbm_bytes_per_launch"] for k in ("k_pre", "k_post") if k in per)
+    phys = per.get("k_physics", {}).get("hbm_bytes_per_launch")       # one persistent kernel per step
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), bench.py --steps 40, %d worlds; summarised by tools/pmc_summary.py" % worlds,
            "calibration": {"pattern": "one coalesced dword per lane, 512 MiB read + 512 MiB written (hs_debug_calibrate)",
                            "fetch_factor": fetch_factor, "write_factor": write_factor},
