@@ -309,40 +309,66 @@ HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, con
     return 4;
 }
 
-HSD bool collide_hulls(const HullRef &A, const HullRef &B, const ClipBuf &cb, RawManifold &m) {
-    WedgeVerts wa, wb;
+// Two lanes of a wave — lane L and lane L + 32, `hi` on the second — run this together on the SAME pair:
+// the kernel is bound by the length of one lane's instruction stream, and the axis tests split cleanly.  The low
+// lane tests A's face normals and the first half of the edge-direction pairs, its partner B's face normals and
+// the second half; they exchange results with cross-lane shuffles and combine them exactly as the sequential
+// loop would (strictly-greater updates, earlier axis wins ties).  Contact generation then runs on the low
+// lane only (it owns the LDS clip scratch); the partner returns false.
+HSD HullRef hull_sel(bool c, const HullRef &a, const HullRef &b) {
+    HullRef r;
+    r.kind = c ? a.kind : b.kind; r.c = vsel(c, a.c, b.c); r.ax = vsel(c, a.ax, b.ax); r.ay = vsel(c, a.ay, b.ay);
+    r.az = vsel(c, a.az, b.az); r.e = vsel(c, a.e, b.e);
+    return r;
+}
+HSD bool collide_hulls(const HullRef &A, const HullRef &B, const ClipBuf &cb, RawManifold &m, const bool hi) {
+    WedgeVerts wa = {}, wb = {};
     if (A.kind == HULL_WEDGE) wedge_verts(A, wa);
     if (B.kind == HULL_WEDGE) wedge_verts(B, wb);
-    float bestA = 0.f; int fa = -1;
-    const int anf = hull_nf(A), bnf = hull_nf(B);
-    for (int f = 0; f < anf; ++f) {
-        V3 fn = hull_fn(A, f);
-        float s = support_min(B, wb, fn) - hull_fd_w(A, wa, f, fn);
-        if (s > 0.f) return false;
-        if (fa < 0 || s > bestA) { bestA = s; fa = f; }
+    // ---- face normals: this lane takes the faces of X against the vertices of Y
+    float bestA, bestB; int fa, fb;
+    {
+        const HullRef X = hull_sel(hi, B, A), Y = hull_sel(hi, A, B);
+        WedgeVerts wx, wy;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { wx.v[i] = vsel(hi, wb.v[i], wa.v[i]); wy.v[i] = vsel(hi, wa.v[i], wb.v[i]); }
+        float best = 0.f; int fx = -1; int sep = 0;
+        const int xnf = hull_nf(X);
+        for (int f = 0; f < xnf; ++f) {
+            V3 fn = hull_fn(X, f);
+            float s = support_min(Y, wy, fn) - hull_fd_w(X, wx, f, fn);
+            if (s > 0.f) { sep = 1; break; }
+            if (fx < 0 || s > best) { best = s; fx = f; }
+        }
+        const float best_o = __shfl_xor(best, 32); const int fx_o = __shfl_xor(fx, 32);
+        if (sep | __shfl_xor(sep, 32)) return false;
+        bestA = hi ? best_o : best; fa = hi ? fx_o : fx;
+        bestB = hi ? best : best_o; fb = hi ? fx : fx_o;
     }
-    float bestB = 0.f; int fb = -1;
-    for (int f = 0; f < bnf; ++f) {
-        V3 fn = hull_fn(B, f);
-        float s = support_min(A, wa, fn) - hull_fd_w(B, wb, f, fn);
-        if (s > 0.f) return false;
-        if (fb < 0 || s > bestB) { bestB = s; fb = f; }
-    }
+    // ---- edge-direction crosses: pairs p = i * bned + j, first half on the low lane
     float bestE = 0.f; int ea = -1, eb = -1; V3 axE = {0.f, 0.f, 0.f};
-    V3 ab = B.c - A.c;
-    const int aned = hull_ned(A), bned = hull_ned(B);
-    for (int i = 0; i < aned; ++i) {
-        V3 ei = hull_ed(A, i);
-        for (int j = 0; j < bned; ++j) {
-            V3 ax = cross(ei, hull_ed(B, j));
+    {
+        V3 ab = B.c - A.c;
+        const int aned = hull_ned(A), bned = hull_ned(B);
+        const int tot = aned * bned, p0 = hi ? tot / 2 : 0, p1 = hi ? tot : tot / 2;
+        int sep = 0;
+        for (int p = p0; p < p1; ++p) {
+            const int i = p / bned, j = p - i * bned;
+            V3 ax = cross(hull_ed(A, i), hull_ed(B, j));
             float l2 = len2(ax);
             if (l2 < 1e-6f) continue;
             ax = ax * (1.f / sqrtf(l2));
             if (dot(ax, ab) < 0.f) ax = -ax;
             float s = support_min(B, wb, ax) - support_max(A, wa, ax);
-            if (s > 0.f) return false;
+            if (s > 0.f) { sep = 1; break; }
             if (ea < 0 || s > bestE) { bestE = s; ea = i; eb = j; axE = ax; }
         }
+        if (sep | __shfl_xor(sep, 32)) return false;
+        const float bE_o = __shfl_xor(bestE, 32); const int ea_o = __shfl_xor(ea, 32), eb_o = __shfl_xor(eb, 32);
+        const V3 ax_o = {__shfl_xor(axE.x, 32), __shfl_xor(axE.y, 32), __shfl_xor(axE.z, 32)};
+        if (hi) return false;                 // the low lane goes on alone
+        // sequential semantics: the second half replaces the first half's best only if strictly greater
+        if (ea_o >= 0 && (ea < 0 || bE_o > bestE)) { bestE = bE_o; ea = ea_o; eb = eb_o; axE = ax_o; }
     }
     float bestF = fmaxf(bestA, bestB);
     if (ea >= 0 && bestE > 0.9f * bestF + 0.0025f) {

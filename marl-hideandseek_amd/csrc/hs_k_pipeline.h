@@ -335,18 +335,20 @@ HSD void phase_detect(const SimState &S, DetectLds &L, int NS, int par) {
 }
 
 // ------------------------------------------------------------------------------------------
-// kClipLanes lanes of every wave take an item (their clip polygons live in the wave's LDS slice).
+// Two lanes per item: lane L < kClipLanes and lane L + 32 run the convex test of the same pair together
+// (collide_hulls); the low lane owns the clip scratch in the wave's LDS slice and writes the manifold.
 struct SatLds { float clipmem[kPhysWaves][kClipWords]; };
 HSD void phase_sat(const SimState &S, SatLds &L, int par) {
+    static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
     const int N = S.N;
     // box-only items from the front of the list, then (starting at a fresh wave) the ramp items from its far end
     const int nbox = load_counter(&S.counters[par * 4 + 0]), nwedge = load_counter(&S.counters[par * 4 + 3]);
     const int wedge0 = (nbox + kClipLanes - 1) / kClipLanes * kClipLanes;
     const int total = wedge0 + nwedge, cap = S.wcnt * (kMaxDDCand + kMaxSCand);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane >= kClipLanes) return;
-    const ClipBuf cb = {L.clipmem[wave], lane};
-    for (int it = wave * kClipLanes + lane; it < total; it += kPhysWaves * kClipLanes) {
+    const bool hi = lane >= kClipLanes;
+    const ClipBuf cb = {L.clipmem[wave], lane & (kClipLanes - 1)};
+    for (int it = wave * kClipLanes + (lane & (kClipLanes - 1)); it < total; it += kPhysWaves * kClipLanes) {
         if (it >= nbox && it < wedge0) continue;
         const int item = it < nbox ? S.satList[it] : S.satList[cap - 1 - (it - wedge0)];
         const int w = item >> 6, idx = item & 63;
@@ -361,11 +363,11 @@ HSD void phase_sat(const SimState &S, SatLds &L, int par) {
         const Q qa = gld4(S.brot, S, a, w);
         const HullRef ha = hull_ref_body(oa, pa, qa);
         RawManifold raw;
-        if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0;
+        if (!hi) { if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0; }
         if (!isdd && bsel >= kMaxWalls) {
             const int p = bsel - kMaxWalls;
             const V3 pn = {S.planes[(0 * kMaxPlanes + p) * N + w], S.planes[(1 * kMaxPlanes + p) * N + w], S.planes[(2 * kMaxPlanes + p) * N + w]};
-            if (collide_hull_plane(ha, pn, S.planes[(3 * kMaxPlanes + p) * N + w], raw)) {
+            if (!hi && collide_hull_plane(ha, pn, S.planes[(3 * kMaxPlanes + p) * N + w], raw)) {
                 ManS m;
                 m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
                 m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
@@ -390,7 +392,7 @@ HSD void phase_sat(const SimState &S, SatLds &L, int par) {
             hb = hull_ref_wall(S.walls[(0 * kMaxWalls + bsel) * N + w], S.walls[(1 * kMaxWalls + bsel) * N + w],
                                S.walls[(2 * kMaxWalls + bsel) * N + w], S.walls[(3 * kMaxWalls + bsel) * N + w]);
         }
-        if (!collide_hulls(ha, hb, cb, raw)) continue;
+        if (!collide_hulls(ha, hb, cb, raw, hi)) continue;
         const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
         const Q qai = qinv(qa);
         if (isdd) {
