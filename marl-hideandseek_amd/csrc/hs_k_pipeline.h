@@ -39,9 +39,9 @@ constexpr int kPhysThreads = HS_PHYS_THREADS;      // 8 waves per workgroup: 2 p
 constexpr int kPhysWorlds = HS_PHYS_WORLDS;        // worlds per workgroup (16 000 worlds -> 250 workgroups on 256 CUs)
 constexpr int kPhysWaves = kPhysThreads / 64;
 
-// List lengths are bumped with atomics (performed in L2) and read by other waves of the workgroup in
-// a later phase: read them past the CU's L1.
-HSD int load_counter(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// List lengths are workgroup-local (LDS, reached through SimState::counters), bumped with atomics and read by
+// other waves in a later phase.
+HSD int load_counter(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- SoA accessors ----
 HSD int bidx(const SimState &S, int c, int slot, int w) { return (c * kNumDSlots + slot) * S.N + w; }
@@ -882,13 +882,16 @@ union PhysLds { DetectLds det; SatLds sat; PreLds pre; PostLds post; };
 __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     __shared__ PhysLds lds;
     __shared__ int chunk_ctr[2];           // next slot-major chunk of phase_body_pos / phase_body_vel
+    __shared__ int list_len[2 * 4];        // work-list lengths (sat box, wall bodies, ddw, sat ramp) x substep parity
     // this workgroup's worlds, and its slices of the work lists / list-length counters
     S.wbeg = blockIdx.x * kPhysWorlds;
     S.wcnt = min(kPhysWorlds, S.N - S.wbeg);
     S.satList += (size_t)S.wbeg * (kMaxDDCand + kMaxSCand);
     S.ddwList += (size_t)S.wbeg * 2;
     S.wallList += (size_t)S.wbeg * kNumDSlots;
-    S.counters += blockIdx.x * 8;
+    // the list lengths live in LDS: every phase starts by reading one, and an L2 round trip there is pure latency
+    if (threadIdx.x < 8) list_len[threadIdx.x] = 0;
+    S.counters = list_len;
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
 #ifdef HS_PHASE_TIMING
     // development aid: wall-clock ticks (100 MHz) per phase of every workgroup -> S.phaseTicks[workgroup][10]

@@ -64,7 +64,8 @@ struct SimState {
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
     int *satList, *wallList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
     long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
-    int *counters;         // [workgroups][2][4] list lengths (sat, wall bodies, ddw), double-buffered by substep parity
+    int *counters;         // [2][4] list lengths (sat box items, wall bodies, ddw, sat ramp items), double-buffered by substep
+                           // parity; set by k_physics to its workgroup's LDS copy
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }
