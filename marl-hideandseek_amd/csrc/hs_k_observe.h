@@ -122,9 +122,9 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         int hit = -1; float best = tmax;
         const V3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
         const int nw = g.numWalls;
+        const WallZ wz = ray_wall_z(o.z, d.z, inv.z);          // the z slab is the same for every wall
         for (int q = 0; q < nw; ++q) {
-            V3 ol = {o.x - g.wall[q][0], o.y - g.wall[q][1], o.z - 1.25f};
-            float t = ray_wall(ol, d, inv, {g.wall[q][2], g.wall[q][3], 1.25f});
+            float t = ray_wall_xy(o.x - g.wall[q][0], o.y - g.wall[q][1], d, inv, g.wall[q][2], g.wall[q][3], wz);
             if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + q; }
         }
         const int np = g.numPlanes;

@@ -77,6 +77,39 @@ HSD float ray_wall(V3 o, V3 d, V3 inv, V3 e) {
     return tn;
 }
 
+// The walls all span z in [0, 2.5], so a ray's z slab is the same for every wall: ray_wall_z evaluates it once per
+// ray and ray_wall_xy folds the x / y slabs of one wall in.  max / min are exact and commutative, so the result is
+// bit-identical to ray_wall's.
+struct WallZ { float tn, tf; bool miss; };
+HSD WallZ ray_wall_z(float oz, float dz, float invz) {
+    WallZ z = {-3.0e38f, 3.0e38f, false};
+    const float o = oz - 1.25f, e = 1.25f;
+    if (dz == 0.f) { z.miss = o < -e || o > e; return z; }
+    float t0 = (-e - o) * invz, t1 = (e - o) * invz;
+    if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+    z.tn = fmaxf(z.tn, t0); z.tf = fminf(z.tf, t1);
+    return z;
+}
+HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, WallZ z) {
+    float tn = -3.0e38f, tf = 3.0e38f;
+    bool miss = z.miss;
+    if (d.x == 0.f) { if (ox < -ex || ox > ex) miss = true; }
+    else {
+        float t0 = (-ex - ox) * inv.x, t1 = (ex - ox) * inv.x;
+        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+    }
+    if (d.y == 0.f) { if (oy < -ey || oy > ey) miss = true; }
+    else {
+        float t0 = (-ey - oy) * inv.y, t1 = (ey - oy) * inv.y;
+        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+    }
+    tn = fmaxf(tn, z.tn); tf = fminf(tf, z.tf);
+    if (miss || tn > tf || tn < 0.f) return -1.f;
+    return tn;
+}
+
 // Squared bounding-sphere radius of a movable hull about its origin, inflated by 2% so that the
 // conservative pre-test below can never reject a ray the exact test would accept.
 HSD float obj_bound_r2(int obj) {
