@@ -185,7 +185,7 @@ int32_t hs_debug_dump_bodies(hs_sim *sim, float *bodies, int32_t *meta);
 int32_t hs_debug_dump_walls(hs_sim *sim, float *walls, int32_t *info);
 
 /* Milliseconds of device time of the last `hs_step`, measured with HIP events on the launch stream when
- * profiling is enabled: [0] the physics pipeline (k_pre, 4 x 9 substep kernels, k_post), [1] k_reset,
+ * profiling is enabled: [0] k_physics (movement / actions, 4 XPBD substeps, rewards), [1] k_reset,
  * [2] k_observe. */
 int32_t hs_set_profiling(hs_sim *sim, int32_t enabled);
 int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);

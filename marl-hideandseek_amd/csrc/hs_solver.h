@@ -1,4 +1,4 @@
-// XPBD contact / joint solver pieces and the actionSystem, shared by the physics pipeline kernels
+// XPBD contact / joint solver pieces and the actionSystem, shared by the phases of the physics kernel
 // (hs_k_pipeline.h).  Replaces madrona::phys' solver (spliced in at src/sim.cpp:1162-1163; engine
 // source absent — DESIGN.md "Engine decisions"): per contact point a normal correction with static
 // friction in the position pass, dynamic friction and restitution 0 in the velocity pass.

@@ -26,10 +26,7 @@ def short(name):
     m = re.search(r"hs::(k_[a-z_]+)(<[^>]*>)?", name)
     if not m:
         return None
-    n = m.group(1)
-    if n == "k_dd":
-        n = "k_dd_pos" if "true" in (m.group(2) or "") else "k_dd_vel"
-    return n
+    return m.group(1)
 
 
 def main():
