@@ -184,7 +184,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.gman, 2 * D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
     HS_ALLOC(S.ndd, N); HS_ALLOC(S.nsc, N); HS_ALLOC(S.ddPair, hs::kMaxDDCand * N); HS_ALLOC(S.scPair, hs::kMaxSCand * N);
     HS_ALLOC(S.wflags, N);
-    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.ddwList, 2 * N);
+    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.bodyList, N * D); HS_ALLOC(S.ddwList, 2 * N);
     HS_ALLOC(S.phaseTicks, 10 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
 #undef HS_ALLOC
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints

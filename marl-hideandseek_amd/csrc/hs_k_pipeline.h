@@ -150,9 +150,10 @@ HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q 
 
 // Per-world bookkeeping at the start of substep `par`: clear the candidate counts, queue worlds with a
 // grab joint for phase_dd.  (The list lengths of a parity are cleared by phase_detect of the other one.)
-HSD void substep_begin(const SimState &S, int slot, int w, int par) {
+HSD void substep_begin_worlds(const SimState &S, int par) {
     const int N = S.N;
-    if (slot == 0) {
+    for (int i = threadIdx.x; i < S.wcnt; i += kPhysThreads) {
+        const int w = S.wbeg + i;
         S.ndd[w] = 0; S.nsc[w] = 0;
         bool grab = false;
         for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther[a * N + w] >= 0;
@@ -161,18 +162,41 @@ HSD void substep_begin(const SimState &S, int slot, int w, int par) {
     }
 }
 
-// First substep only; the later substeps are integrated at the end of phase_body_vel.
-HSD void phase_integrate(const SimState &S, int NS, int par) {
+// First substep only; the later substeps are integrated at the end of phase_body_vel.  Also compacts the
+// workgroup's existing bodies into bodyList (slot-major order kept, so the lanes of a wave still mostly share
+// a hull type): about a third of the box slots are empty, and the slot-major passes of body_pos / body_vel
+// would carry them as idle lanes in every substep.  `scratch` is kPhysWaves * 4 + 1 ints of LDS.
+HSD int phase_integrate(const SimState &S, int NS, int par, int *scratch) {
     const int N = S.N;
-    for (int t = threadIdx.x; t < NS * S.wcnt; t += kPhysThreads) {
-        const int slot = t / S.wcnt, w = S.wbeg + (t - slot * S.wcnt);
-        substep_begin(S, slot, w, par);
-        const int meta = S.bmeta[slot * N + w];
-        if (meta == 0) continue;
-        V3 lin = {0.f, 0.f, 0.f}, ang = {0.f, 0.f, 0.f};
-        if (meta_resp(meta) == RESP_DYNAMIC) { lin = gld3(S.blin, S, slot, w); ang = gld3(S.bang, S, slot, w); }
-        integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang, par);
+    substep_begin_worlds(S, par);
+    const int total = NS * S.wcnt, nchunks = (total + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *const chunk_base = scratch;                 // [nchunks + 1], nchunks <= 17
+    for (int c = wave; c < nchunks; c += kPhysWaves) {
+        const int t = c * 64 + lane;
+        int meta = 0, slot = 0, w = 0;
+        if (t < total) { slot = t / S.wcnt; w = S.wbeg + (t - slot * S.wcnt); meta = S.bmeta[slot * N + w]; }
+        const unsigned long long m = __ballot(meta != 0);
+        if (lane == 0) chunk_base[c + 1] = __popcll(m);
+        if (meta != 0) {
+            V3 lin = {0.f, 0.f, 0.f}, ang = {0.f, 0.f, 0.f};
+            if (meta_resp(meta) == RESP_DYNAMIC) { lin = gld3(S.blin, S, slot, w); ang = gld3(S.bang, S, slot, w); }
+            integrate_body(S, w, slot, meta, gld3(S.bpos, S, slot, w), gld4(S.brot, S, slot, w), lin, ang, par);
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { chunk_base[0] = 0; for (int c = 0; c < nchunks; ++c) chunk_base[c + 1] += chunk_base[c]; }
+    __syncthreads();
+    for (int c = wave; c < nchunks; c += kPhysWaves) {
+        const int t = c * 64 + lane;
+        int meta = 0, slot = 0, w = 0;
+        if (t < total) { slot = t / S.wcnt; w = S.wbeg + (t - slot * S.wcnt); meta = S.bmeta[slot * N + w]; }
+        const unsigned long long m = __ballot(meta != 0);
+        if (meta != 0) S.bodyList[chunk_base[c] + __popcll(m & ((1ull << lane) - 1ull))] = (w << 5) | slot;
+    }
+    const int nbodies = chunk_base[nchunks];
+    __syncthreads();
+    return nbodies;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -610,18 +634,17 @@ HSD int next_chunk(int *ctr) {
     if ((threadIdx.x & 63) == 0) c = atomicAdd(ctr, 1);
     return __shfl(c, 0);
 }
-HSD void phase_body_pos(const SimState &S, int NS, int par, int *chunk_ctr) {
+HSD void phase_body_pos(const SimState &S, int nbodies, int par, int *chunk_ctr) {
     const int nwall = load_counter(&S.counters[par * 4 + 1]);
     for (int it = threadIdx.x; it < nwall; it += kPhysThreads) {
         const int item = S.wallList[it];
         body_pos_item<true>(S, item & 31, item >> 5, par);
     }
-    const int total = NS * S.wcnt;
-    for (int c = next_chunk(chunk_ctr); c * 64 < total; c = next_chunk(chunk_ctr)) {
+    for (int c = next_chunk(chunk_ctr); c * 64 < nbodies; c = next_chunk(chunk_ctr)) {
         const int t = c * 64 + (threadIdx.x & 63);
-        if (t >= total) continue;
-        const int slot = t / S.wcnt;
-        body_pos_item<false>(S, slot, S.wbeg + (t - slot * S.wcnt), par);
+        if (t >= nbodies) continue;
+        const int item = S.bodyList[t];
+        body_pos_item<false>(S, item & 31, item >> 5, par);
     }
 }
 
@@ -631,7 +654,6 @@ HSD void phase_body_pos(const SimState &S, int NS, int par, int *chunk_ctr) {
 template <bool NEXT, bool WALLED>
 HSD void body_vel_item(const SimState &S, int slot, int w, int par, int par_next) {
     const int N = S.N;
-    if (NEXT && !WALLED) substep_begin(S, slot, w, par_next);
     const int meta = S.bmeta[slot * N + w];
     if (meta == 0) return;
     if (meta_resp(meta) != RESP_DYNAMIC) {
@@ -675,19 +697,19 @@ HSD void body_vel_item(const SimState &S, int slot, int w, int par, int par_next
     else gbody_store_vel(S, w, slot, me);
 }
 template <bool NEXT>
-HSD void phase_body_vel(const SimState &S, int NS, int par, int par_next, int *chunk_ctr) {
+HSD void phase_body_vel(const SimState &S, int nbodies, int par, int par_next, int *chunk_ctr) {
     const int nwall = load_counter(&S.counters[par * 4 + 1]);
     for (int it = threadIdx.x; it < nwall; it += kPhysThreads) {
         const int item = S.wallList[it];
         body_vel_item<NEXT, true>(S, item & 31, item >> 5, par, par_next);
     }
-    const int total = NS * S.wcnt;
-    for (int c = next_chunk(chunk_ctr); c * 64 < total; c = next_chunk(chunk_ctr)) {
+    for (int c = next_chunk(chunk_ctr); c * 64 < nbodies; c = next_chunk(chunk_ctr)) {
         const int t = c * 64 + (threadIdx.x & 63);
-        if (t >= total) continue;
-        const int slot = t / S.wcnt;
-        body_vel_item<NEXT, false>(S, slot, S.wbeg + (t - slot * S.wcnt), par, par_next);
+        if (t >= nbodies) continue;
+        const int item = S.bodyList[t];
+        body_vel_item<NEXT, false>(S, item & 31, item >> 5, par, par_next);
     }
+    if (NEXT) substep_begin_worlds(S, par_next);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -882,6 +904,7 @@ union PhysLds { DetectLds det; SatLds sat; PreLds pre; PostLds post; };
 __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     __shared__ PhysLds lds;
     __shared__ int chunk_ctr[2];           // next slot-major chunk of phase_body_pos / phase_body_vel
+    __shared__ int integ_scratch[kNumDSlots + 2];   // chunk offsets of the compact body list
     __shared__ int list_len[2 * 4];        // work-list lengths (sat box, wall bodies, ddw, sat ramp) x substep parity
     // this workgroup's worlds, and its slices of the work lists / list-length counters
     S.wbeg = blockIdx.x * kPhysWorlds;
@@ -889,6 +912,7 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     S.satList += (size_t)S.wbeg * (kMaxDDCand + kMaxSCand);
     S.ddwList += (size_t)S.wbeg * 2;
     S.wallList += (size_t)S.wbeg * kNumDSlots;
+    S.bodyList += (size_t)S.wbeg * kNumDSlots;
     // the list lengths live in LDS: every phase starts by reading one, and an L2 round trip there is pure latency
     if (threadIdx.x < 8) list_len[threadIdx.x] = 0;
     S.counters = list_len;
@@ -902,9 +926,10 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
 #endif
     phase_pre(S, lds.pre);
     HS_TICK(0)
+    int nbodies = 0;
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const int par = sub & 1;
-        if (sub == 0) { phase_integrate(S, NS, par); __syncthreads(); }
+        if (sub == 0) nbodies = phase_integrate(S, NS, par, integ_scratch);
         HS_TICK(1)
         if (threadIdx.x == 0) { chunk_ctr[0] = 0; chunk_ctr[1] = 0; }
         phase_detect(S, lds.det, NS, par);
@@ -915,14 +940,14 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
         phase_dd<true>(S, par);
         __syncthreads();
         HS_TICK(4)
-        phase_body_pos(S, NS, par, &chunk_ctr[0]);
+        phase_body_pos(S, nbodies, par, &chunk_ctr[0]);
         __syncthreads();
         HS_TICK(5)
         phase_dd<false>(S, par);
         __syncthreads();
         HS_TICK(6)
-        if (sub + 1 < kNumSubsteps) phase_body_vel<true>(S, NS, par, par ^ 1, &chunk_ctr[1]);
-        else phase_body_vel<false>(S, NS, par, 0, &chunk_ctr[1]);
+        if (sub + 1 < kNumSubsteps) phase_body_vel<true>(S, nbodies, par, par ^ 1, &chunk_ctr[1]);
+        else phase_body_vel<false>(S, nbodies, par, 0, &chunk_ctr[1]);
         __syncthreads();
         HS_TICK(7)
     }

@@ -62,6 +62,7 @@ struct SimState {
     int *ddPair, *scPair;  // [kMaxDDCand][N] a | b << 8 ; [kMaxSCand][N] body | static << 8
     int *wflags;           // [N]         1 = world has a grab joint
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
+    int *bodyList;         // [N][17] existing bodies of a workgroup's worlds, compacted once per step (w << 5 | slot)
     int *satList, *wallList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
     long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
     int *counters;         // [2][4] list lengths (sat box items, wall bodies, ddw, sat ramp items), double-buffered by substep
