@@ -247,38 +247,56 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
         if (l == 0) { dw.ndd = 0; dw.nsc = 0; }
     }
     __syncthreads();
-    // lane l owns body slots l, l + 8 (and lane 0 slot 16 when 6 agents are configured)
+    // lane l owns body slots l, l + 8 (and lane 0 slot 16 when 6 agents are configured).  The loops run over the
+    // OTHER body / the wall, each read from LDS once and tested against all of the lane's slots.
     int tot_items = 0;
     unsigned dd_mask[JB] = {}; unsigned long long s_mask[JB] = {};
     int bdd[JB] = {}, bsc[JB] = {}, add[JB] = {}, asc[JB] = {};
+    bool have[JB], dynamic[JB]; V3 lo[JB], hi[JB];
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
         const int slot = l + jb * G;
-        if (!wok || slot >= NS) continue;
-        const int meta = dw.meta[slot];
-        if (meta == 0) continue;
-        const bool dynamic = meta_resp(meta) == RESP_DYNAMIC;
-        const V3 lo = {dw.lo[slot][0], dw.lo[slot][1], dw.lo[slot][2]}, hi = {dw.hi[slot][0], dw.hi[slot][1], dw.hi[slot][2]};
-        for (int j = slot + 1; j < NS; ++j) {
+        const int meta = (wok && slot < NS) ? dw.meta[slot] : 0;
+        have[jb] = meta != 0;
+        dynamic[jb] = have[jb] && meta_resp(meta) == RESP_DYNAMIC;
+        lo[jb] = {0.f, 0.f, 0.f}; hi[jb] = {0.f, 0.f, 0.f};
+        if (have[jb]) { lo[jb] = {dw.lo[slot][0], dw.lo[slot][1], dw.lo[slot][2]}; hi[jb] = {dw.hi[slot][0], dw.hi[slot][1], dw.hi[slot][2]}; }
+    }
+    if (wok) {
+        for (int j = 1; j < NS; ++j) {
             const int mj = dw.meta[j];
-            if (mj == 0 || !(dynamic || meta_resp(mj) == RESP_DYNAMIC)) continue;
-            if (lo.x <= dw.hi[j][0] && dw.lo[j][0] <= hi.x && lo.y <= dw.hi[j][1] && dw.lo[j][1] <= hi.y &&
-                lo.z <= dw.hi[j][2] && dw.lo[j][2] <= hi.z) dd_mask[jb] |= 1u << j;
-        }
-        if (dynamic) {
-            for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
-            for (int k = 0; k < nwl; ++k) {
-                const float cx = dw.wall[k][0], cy = dw.wall[k][1], hx = dw.wall[k][2], hy = dw.wall[k][3];
-                if (lo.x <= cx + hx && cx - hx <= hi.x && lo.y <= cy + hy && cy - hy <= hi.y && lo.z <= 2.5f && 0.f <= hi.z)
-                    s_mask[jb] |= 1ull << k;
+            if (mj == 0) continue;
+            const bool dynj = meta_resp(mj) == RESP_DYNAMIC;
+            const V3 loj = {dw.lo[j][0], dw.lo[j][1], dw.lo[j][2]}, hij = {dw.hi[j][0], dw.hi[j][1], dw.hi[j][2]};
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) {
+                if (have[jb] && l + jb * G < j && (dynamic[jb] || dynj) &&
+                    lo[jb].x <= hij.x && loj.x <= hi[jb].x && lo[jb].y <= hij.y && loj.y <= hi[jb].y &&
+                    lo[jb].z <= hij.z && loj.z <= hi[jb].z) dd_mask[jb] |= 1u << j;
             }
         }
+        for (int k = 0; k < nwl; ++k) {
+            const float cx = dw.wall[k][0], cy = dw.wall[k][1], hx = dw.wall[k][2], hy = dw.wall[k][3];
+            const float wx0 = cx - hx, wx1 = cx + hx, wy0 = cy - hy, wy1 = cy + hy;
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb) {
+                if (dynamic[jb] && lo[jb].x <= wx1 && wx0 <= hi[jb].x && lo[jb].y <= wy1 && wy0 <= hi[jb].y &&
+                    lo[jb].z <= 2.5f && 0.f <= hi[jb].z) s_mask[jb] |= 1ull << k;
+            }
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        const int slot = l + jb * G;
+        if (!have[jb]) continue;
+        if (dynamic[jb]) for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
         const int cdd = __popc(dd_mask[jb]), csc = __popcll(s_mask[jb]);
         if (cdd) bdd[jb] = atomicAdd(&dw.ndd, cdd);
         if (csc) bsc[jb] = atomicAdd(&dw.nsc, csc);
         add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
+        (void)slot;
     }
     // ---- reserve space in the work lists: wave scans, workgroup scan, one atomic per list.
     // Convex-test items that involve a ramp (wedge hull) are kept apart from the box-only ones — they go
