@@ -206,7 +206,6 @@ struct DetectWorld {
     int meta[kNumDSlots];
     float lo[kNumDSlots][3], hi[kNumDSlots][3];
     float wall[kMaxWalls][4];
-    int ndd, nsc;
 };
 
 // One pass: kPhysThreads / kDetectLanes worlds starting at local index wfirst.  List space is
@@ -244,7 +243,6 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
 #pragma unroll
             for (int c = 0; c < 4; ++c) dw.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
         }
-        if (l == 0) { dw.ndd = 0; dw.nsc = 0; }
     }
     __syncthreads();
     // lane l owns body slots l, l + 8 (and lane 0 slot 16 when 6 agents are configured).  The loops run over the
@@ -285,18 +283,24 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
             }
         }
     }
+    // candidate slots in the world's lists: prefix sums in body-slot order (slots l of all lanes, then l + 8, ...),
+    // i.e. the oracle's candidate order — so even the pairs dropped beyond the capacity are the oracle's
+    int tot_dd = 0, tot_sc = 0;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
-        const int slot = l + jb * G;
-        if (!have[jb]) continue;
         if (dynamic[jb]) for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
         const int cdd = __popc(dd_mask[jb]), csc = __popcll(s_mask[jb]);
-        if (cdd) bdd[jb] = atomicAdd(&dw.ndd, cdd);
-        if (csc) bsc[jb] = atomicAdd(&dw.nsc, csc);
+        int in_dd = cdd, in_sc = csc;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const int y0 = __shfl_up(in_dd, d, G), y1 = __shfl_up(in_sc, d, G);
+            if (l >= d) { in_dd += y0; in_sc += y1; }
+        }
+        bdd[jb] = tot_dd + in_dd - cdd; bsc[jb] = tot_sc + in_sc - csc;
+        tot_dd += __shfl(in_dd, G - 1, G); tot_sc += __shfl(in_sc, G - 1, G);
         add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
-        (void)slot;
     }
     // ---- reserve space in the work lists: wave scans, workgroup scan, one atomic per list.
     // Convex-test items that involve a ramp (wedge hull) are kept apart from the box-only ones — they go
@@ -359,8 +363,7 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
         if (asc[jb] > 0) S.wallList[wbase2++] = (w << 5) | slot;      // bodies with static candidates: own work items
     }
     if (push_ddw) S.ddwList[bbase[2] + wtot[2][wv] + incl[2] - 1] = w;
-    __syncthreads();
-    if (wok && l == 0) { S.ndd[w] = dw.ndd; S.nsc[w] = dw.nsc; }
+    if (wok && l == 0) { S.ndd[w] = tot_dd; S.nsc[w] = tot_sc; }
     // ---- the static-candidate range of the owned bodies joins their ground-manifold word (phase_integrate)
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
