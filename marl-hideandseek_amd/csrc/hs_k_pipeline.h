@@ -516,7 +516,8 @@ HSD void phase_dd(const SimState &S, int par) {
     const int total = load_counter(&S.counters[par * 4 + 2]);
     const int q = threadIdx.x % GL;
     const int gbit0 = (threadIdx.x & 63) / GL * GL;               // first lane of this group in the wave
-    for (int it = threadIdx.x / GL; ; it += kPhysThreads / GL) {
+    // consecutive worlds of the list go to different waves: a wave runs until the slowest of its worlds is done
+    for (int it = ((threadIdx.x & 63) / GL) * kPhysWaves + (threadIdx.x >> 6); ; it += kPhysThreads / GL) {
         if (__ballot(it < total) == 0ull) break;                  // wave-uniform exit
         const bool live = it < total;
         const int w = live ? S.ddwList[it] : 0;
