@@ -162,3 +162,36 @@ def test_stream_entry_points_match_blocking_api(oracle):
     assert np.array_equal(bits(a.debug_bodies()[0]), bits(b.debug_bodies()[0]))
     with pytest.raises(ValueError):
         b.stream_step(strm.cuda_stream, obs)
+
+
+def test_replay_log_round_trip(oracle, tmp_path):
+    """The replay-log format of scripts/jax_infer.py:125 / src/viewer.cpp:13-26,185-215: record a run, play it back
+    in a fresh simulator, and get the recorded body state and observations at every step."""
+    import torch
+    import gpu_hideseek
+    from gpu_hideseek import replay
+    n = 24
+    sim, ref, gt = make_pair(oracle, n, seed=6)
+    ref.close()
+    path = tmp_path / "run.log"
+    rng = np.random.default_rng(3)
+    seen = []
+    with open(path, "wb") as f:
+        for t in range(12):
+            gt["action"][:, :3] = torch.from_numpy(rng.integers(0, 11, size=(n * 4, 3)).astype(np.int32)).cuda()
+            sim.step()
+            replay.record_step(sim, f)
+            seen.append((sim.debug_bodies()[0].copy(), gt["self_data"].clone(), gt["lidar"].clone(), gt["global_positions"].clone()))
+    log = replay.read_log(str(path), n)
+    assert log.shape == (12, n, 1392)
+    player = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=n, sim_flags=0, rand_seed=6, min_hiders=2,
+        max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+    player.init()
+    for t in (0, 5, 11, 3):
+        replay.replay_step(player, log, t)
+        bodies, self_data, lidar, gpos = seen[t]
+        assert np.array_equal(bits(player.debug_bodies()[0]), bits(bodies)), t
+        assert torch.equal(player.self_data_tensor().to_torch().view(torch.int32), self_data.view(torch.int32)), t
+        assert torch.equal(player.lidar_tensor().to_torch().view(torch.int32), lidar.view(torch.int32)), t
+        assert torch.equal(player.global_positions_tensor().to_torch().view(torch.int32), gpos.view(torch.int32)), t
