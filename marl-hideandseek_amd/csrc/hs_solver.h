@@ -62,10 +62,13 @@ HSD float gen_inv_mass(const BodyS &b, V3 r, V3 n) {
     V3 rn = cross(r, n);
     return b.invM + dot(rn, sym_mul(b.Iw, rn));
 }
+// q += 0.5 * (0,dth) * q, then one Newton step of 1/sqrt(|q|^2) from 1 (DESIGN.md "Engine decisions")
 HSD Q quat_add_rotation(Q q, V3 dth) {
     Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
     Q r = {q.w + 0.5f * dq.w, q.x + 0.5f * dq.x, q.y + 0.5f * dq.y, q.z + 0.5f * dq.z};
-    return qnormalize(r);
+    const float n2 = ((r.w * r.w + r.x * r.x) + r.y * r.y) + r.z * r.z;
+    const float k = 1.5f - 0.5f * n2;
+    return {r.w * k, r.x * k, r.y * k, r.z * k};
 }
 HSD bool has_mass(const BodyS &b) { return b.invM != 0.f || b.invI.z != 0.f || b.invI.x != 0.f || b.invI.y != 0.f; }
 
