@@ -28,6 +28,7 @@ constexpr int kNumPrepSteps = 96;
 constexpr int kEpisodeLen = 240;
 constexpr int kNumSubsteps = 4;          // setupPhysicsStepTasks(..., 4, XPBD)  src/sim.cpp:1162-1163
 constexpr float kSubstepH = (1.f / 30.f) / 4.f;
+constexpr float kInvSubstepH = 120.f;
 constexpr float kGravityZ = -9.8f;
 constexpr float kMaxDepenVel = 3.f;
 constexpr int kMaxDDCand = 16;

@@ -58,6 +58,12 @@ HSD void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 HSD void st4(float *p, Q q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 
 HSD V3 apply_inv_inertia(const BodyS &b, V3 v) { return sym_mul(b.Iw, v); }
+// |d|^2 times the generalised inverse mass along d / |d| for an unnormalised d (d2 = |d|^2): lets the friction
+// corrections skip the sqrt / divide of normalising the tangent (same expressions as the oracle's)
+HSD float gen_inv_mass_sq(const BodyS &b, V3 r, V3 d, float d2) {
+    V3 rd = cross(r, d);
+    return b.invM * d2 + dot(rd, sym_mul(b.Iw, rd));
+}
 HSD float gen_inv_mass(const BodyS &b, V3 r, V3 n) {
     V3 rn = cross(r, n);
     return b.invM + dot(rn, sym_mul(b.Iw, rn));
@@ -121,14 +127,13 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
     V3 dpt = dp - n * dot(dp, n);
     float lt2 = len2(dpt);
     if (lt2 > 1e-12f) {
-        float lt = sqrtf(lt2);
-        V3 t = dpt * (1.f / lt);
-        float wtA = gen_inv_mass(A, rAw, t);
-        float wtB = HAS_B ? gen_inv_mass(B, rBw, t) : 0.f;
+        float wtA = gen_inv_mass_sq(A, rAw, dpt, lt2);
+        float wtB = HAS_B ? gen_inv_mass_sq(B, rBw, dpt, lt2) : 0.f;
         float wts = wtA + wtB;
         if (wts > 0.f) {
-            float lamT = lt / wts;
-            if (lamT < muS * lam) apply_pos_impulse<HAS_B>(A, rAw, B, rBw, t * lamT);
+            // static friction holds while |dpt| / w(t) < muS * lam  <=>  lt2^3 < (muS * lam * wts)^2
+            float lim = (muS * lam) * wts;
+            if ((lt2 * lt2) * lt2 < lim * lim) apply_pos_impulse<HAS_B>(A, rAw, B, rBw, dpt * (lt2 / wts));
         }
     }
     return lam;
@@ -137,7 +142,6 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
 // One contact point of the velocity pass (dynamic friction, restitution 0).
 template <bool HAS_B>
 HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float lamN, float muD) {
-    const float h = kSubstepH;
     if (!(lamN > 0.f)) return;
     V3 rAw = qrot(A.rot, rAl);
     V3 rBw = HAS_B ? qrot(B.rot, rBl) : V3{0.f, 0.f, 0.f};
@@ -146,21 +150,20 @@ HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float la
     if (HAS_B && B.invM + B.invI.x + B.invI.y + B.invI.z != 0.f) v = v - (B.lin + cross(B.ang, rBw));
     float vn = dot(n, v);
     V3 vt = v - n * vn;
-    float vtl = len(vt);
+    float vt2 = len2(vt);
     V3 dv = -(n * vn);
-    if (vtl > 1e-9f) {
-        float fn = lamN / (h * h);
-        float mag = fminf(h * muD * fn, vtl);
+    if (vt2 > 1e-18f) {
+        float vtl = sqrtf(vt2);
+        float mag = fminf((muD * lamN) * kInvSubstepH, vtl);
         dv = dv - vt * (mag / vtl);
     }
-    float dvl = len(dv);
-    if (!(dvl > 1e-9f)) return;
-    V3 dir = dv * (1.f / dvl);
-    float wA = gen_inv_mass(A, rAw, dir);
-    float wB = HAS_B ? gen_inv_mass(B, rBw, dir) : 0.f;
+    float dv2 = len2(dv);
+    if (!(dv2 > 1e-18f)) return;
+    float wA = gen_inv_mass_sq(A, rAw, dv, dv2);
+    float wB = HAS_B ? gen_inv_mass_sq(B, rBw, dv, dv2) : 0.f;
     float ws = wA + wB;
     if (!(ws > 0.f)) return;
-    V3 p = dir * (dvl / ws);
+    V3 p = dv * (dv2 / ws);
     A.lin = A.lin + p * A.invM;
     A.ang = A.ang + apply_inv_inertia(A, cross(rAw, p));
     if (HAS_B) {

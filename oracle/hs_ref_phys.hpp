@@ -19,6 +19,7 @@
 namespace hsref {
 
 constexpr float kSubstepH = (1.f / 30.f) / 4.f;
+constexpr float kInvSubstepH = 120.f;
 constexpr float kGravityZ = -9.8f;            // sim.cpp:1360
 // Candidate-pair capacities per world per substep (pairs whose AABBs overlap; measured maxima on
 // the benchmark workload are 6 accepted body-body and 9 accepted body-wall manifolds).  Pairs
@@ -379,6 +380,13 @@ static inline BodyMass body_mass(const DBody &b) {
     return {obj_inv_mass(b.objType), invI, world_inv_inertia(b.rot, invI)};
 }
 static inline V3 apply_inv_inertia(const BodyMass &bm, V3 v) { return sym_mul(bm.Iw, v); }
+// For a direction d that is NOT normalised: |d|^2 times the generalised inverse mass along d/|d|
+// (d2 = |d|^2).  The friction corrections below are written with it so that they need no sqrt / divide to
+// normalise the tangent: correction along t = d/|d| of size |d| / w(t) equals d * (|d|^2 / w'(d)).
+static inline float gen_inv_mass_sq(const BodyMass &bm, V3 r, V3 d, float d2) {
+    V3 rd = cross(r, d);
+    return bm.invM * d2 + dot(rd, sym_mul(bm.Iw, rd));
+}
 static inline float gen_inv_mass(const BodyMass &bm, V3 r, V3 n) {
     V3 rn = cross(r, n);
     return bm.invM + dot(rn, sym_mul(bm.Iw, rn));
@@ -452,14 +460,13 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
         V3 dpt = dp - n * dot(dp, n);
         float lt2 = len2(dpt);
         if (lt2 > 1e-12f) {
-            float lt = sqrtf(lt2);
-            V3 t = dpt * (1.f / lt);
-            float wtA = gen_inv_mass(ma, rAw, t);
-            float wtB = B ? gen_inv_mass(mb, rBw, t) : 0.f;
+            float wtA = gen_inv_mass_sq(ma, rAw, dpt, lt2);
+            float wtB = B ? gen_inv_mass_sq(mb, rBw, dpt, lt2) : 0.f;
             float wts = wtA + wtB;
             if (wts > 0.f) {
-                float lamT = lt / wts;
-                if (lamT < m.muS * lam) apply_pos_impulse(A, ma, rAw, B, mb, rBw, t * lamT);
+                // static friction holds while |dpt| / w(t) < muS * lam  <=>  lt2^3 < (muS * lam * wts)^2
+                float lim = (m.muS * lam) * wts;
+                if ((lt2 * lt2) * lt2 < lim * lim) apply_pos_impulse(A, ma, rAw, B, mb, rBw, dpt * (lt2 / wts));
             }
         }
     }
@@ -476,7 +483,6 @@ static inline void apply_vel_impulse(DBody *A, const BodyMass &ma, V3 rA, DBody 
 }
 
 static inline void solve_manifold_velocities(World &w, const Manifold &m) {
-    const float h = kSubstepH;
     DBody *A = &w.d[m.a];
     DBody *B = m.b >= 0 ? &w.d[m.b] : nullptr;
     BodyMass ma = body_mass(*A);
@@ -493,21 +499,21 @@ static inline void solve_manifold_velocities(World &w, const Manifold &m) {
         if (B && mb.invM + mb.invI.x + mb.invI.y + mb.invI.z != 0.f) v = v - (B->lin + cross(B->ang, rBw));
         float vn = dot(n, v);
         V3 vt = v - n * vn;
-        float vtl = len(vt);
+        float vt2 = len2(vt);
         V3 dv = -(n * vn);                      // restitution 0: kill the normal component
-        if (vtl > 1e-9f) {
-            float fn = lamN / (h * h);
-            float mag = fminf(h * m.muD * fn, vtl);
+        if (vt2 > 1e-18f) {
+            // dynamic friction: |dv_t| <= h * muD * f_n with f_n = lamN / h^2, i.e. muD * lamN / h
+            float vtl = sqrtf(vt2);
+            float mag = fminf((m.muD * lamN) * kInvSubstepH, vtl);
             dv = dv - vt * (mag / vtl);
         }
-        float dvl = len(dv);
-        if (!(dvl > 1e-9f)) continue;
-        V3 dir = dv * (1.f / dvl);
-        float wA = gen_inv_mass(ma, rAw, dir);
-        float wB = B ? gen_inv_mass(mb, rBw, dir) : 0.f;
+        float dv2 = len2(dv);
+        if (!(dv2 > 1e-18f)) continue;
+        float wA = gen_inv_mass_sq(ma, rAw, dv, dv2);
+        float wB = B ? gen_inv_mass_sq(mb, rBw, dv, dv2) : 0.f;
         float ws = wA + wB;
         if (!(ws > 0.f)) continue;
-        apply_vel_impulse(A, ma, rAw, B, mb, rBw, dir * (dvl / ws));
+        apply_vel_impulse(A, ma, rAw, B, mb, rBw, dv * (dv2 / ws));
     }
 }
 
