@@ -207,6 +207,40 @@ HSD bool collide_hull_plane(const HullRef &A, V3 pn, float pd, RawManifold &m) {
     return np > 0;
 }
 
+// The ground-manifold form of collide_hull_plane: same vertex order, same selection and the same expressions, but
+// it keeps per contact only what the ground solve reads — the vertex index and the plane offset dot(pB, n) with
+// n = -pn — instead of the points (this runs for every body in every substep).  Returns np; idx packs 3 bits per
+// contact.
+HSD int ground_manifold(const HullRef &A, V3 pn, float pd, int *idx, float off[4]) {
+    int np = 0, vi = 0; float depth[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nv = hull_nv(A);
+    const V3 n = -pn;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= nv) continue;
+        V3 v = hull_v(A, i);
+        float dist = dot(pn, v) - pd;
+        if (!(dist < 0.f)) continue;
+        float dep = -dist;
+        V3 pb = v - pn * dist;
+        int slot;
+        if (np < 4) { slot = np; np++; }
+        else {
+            int mi = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (depth[k] < depth[mi]) mi = k;
+            if (!(dep > depth[mi])) continue;
+            slot = mi;
+        }
+        const float o = dot(pb, n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k == slot) { depth[k] = dep; off[k] = o; vi = (vi & ~(7 << (3 * k))) | (i << (3 * k)); }
+    }
+    *idx = vi;
+    return np;
+}
+
 HSD void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3 *c1, V3 *c2) {
     V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);

@@ -134,13 +134,14 @@ HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q 
     // ground plane (plane 0) manifold at the integrated pose; phase_detect adds the static-candidate range
     int gword = 0;
     if (meta_resp(meta) == RESP_DYNAMIC && S.numPlanes[w] >= 1) {
-        RawManifold raw;
         const V3 pn = {S.planes[(0 * kMaxPlanes) * N + w], S.planes[(1 * kMaxPlanes) * N + w], S.planes[(2 * kMaxPlanes) * N + w]};
-        if (collide_hull_plane(hb, pn, S.planes[(3 * kMaxPlanes) * N + w], raw)) {
-            gword |= raw.np;
+        int vidx; float off[4] = {0.f, 0.f, 0.f, 0.f};
+        const int np = ground_manifold(hb, pn, S.planes[(3 * kMaxPlanes) * N + w], &vidx, off);
+        if (np > 0) {
+            gword |= np | (vidx << 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (j < raw.np) { gword |= raw.vidx[j] << (4 + 3 * j); S.goff[bidx(S, j, slot, w)] = dot(raw.pB[j], raw.n); }
+                if (j < np) S.goff[bidx(S, j, slot, w)] = off[j];
                 S.glam[bidx(S, j, slot, w)] = 0.f;
             }
         }
