@@ -73,7 +73,9 @@ HSD Q quat_add_rotation(Q q, V3 dth) {
     Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
     Q r = {q.w + 0.5f * dq.w, q.x + 0.5f * dq.x, q.y + 0.5f * dq.y, q.z + 0.5f * dq.z};
     const float n2 = ((r.w * r.w + r.x * r.x) + r.y * r.y) + r.z * r.z;
-    const float k = 1.5f - 0.5f * n2;
+    // small updates (|dth| < 0.2 rad: every contact correction, ordinary integration); a joint that snaps a badly
+    // misaligned body round can turn it by radians in one go and gets the exact normalisation
+    const float k = n2 < 1.01f ? 1.5f - 0.5f * n2 : 1.f / sqrtf(n2);
     return {r.w * k, r.x * k, r.y * k, r.z * k};
 }
 HSD bool has_mass(const BodyS &b) { return b.invM != 0.f || b.invI.z != 0.f || b.invI.x != 0.f || b.invI.y != 0.f; }

@@ -142,6 +142,13 @@ def _load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HIP runtime (same SONAME as the system one).  If libhideseek pulled the
+    # system copy in first, a later `import torch` would find "No HIP GPUs" — and the reference's scripts import
+    # gpu_hideseek before torch (scripts/benchmark.py:1-2).  Loading torch first makes both share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_LIB_PATH):
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `python __graft_entry__.py build` "

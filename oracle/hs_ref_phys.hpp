@@ -391,7 +391,8 @@ static inline float gen_inv_mass(const BodyMass &bm, V3 r, V3 n) {
     V3 rn = cross(r, n);
     return bm.invM + dot(rn, sym_mul(bm.Iw, rn));
 }
-// q += 0.5 * (0,dth) * q, then ONE Newton step of 1/sqrt(|q|^2) from 1 instead of an exact normalisation:
+// q += 0.5 * (0,dth) * q, then — for small updates — ONE Newton step of 1/sqrt(|q|^2) from 1 instead of an exact
+// normalisation:
 // |q|^2 = 1 + |dth|^2/4 after the update, so the step leaves a norm error of 3/8 (|dth|^2/4)^2 (< 2e-5 even for a
 // body tumbling at 20 rad/s) that the next update corrects again; it costs 4 multiplies instead of sqrt + divide
 // in the innermost loop of the solver.
@@ -399,7 +400,9 @@ static inline Q quat_add_rotation(Q q, V3 dth) {
     Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
     Q r = {q.w + 0.5f * dq.w, q.x + 0.5f * dq.x, q.y + 0.5f * dq.y, q.z + 0.5f * dq.z};
     const float n2 = ((r.w * r.w + r.x * r.x) + r.y * r.y) + r.z * r.z;
-    const float k = 1.5f - 0.5f * n2;
+    // small updates (|dth| < 0.2 rad: every contact correction, ordinary integration); a joint that snaps a badly
+    // misaligned body round can turn it by radians in one go and gets the exact normalisation
+    const float k = n2 < 1.01f ? 1.5f - 0.5f * n2 : 1.f / sqrtf(n2);
     return {r.w * k, r.x * k, r.y * k, r.z * k};
 }
 // positional impulse p applied at rA (on A, gets -p) and rB (on B, gets +p); r's are world offsets

@@ -107,3 +107,26 @@ def test_collide_face_and_separation(oracle):
     c = L.hsref_collide(6, f([0, 0, 0]), ident, 2, f([0, -0.5, 1.1]), f([0.9659258, 0.2588190, 0, 0]), n, pA, pB)
     assert c >= 1
     assert np.isfinite(np.array(n[:])).all() and abs(np.linalg.norm(n[:]) - 1) < 1e-5
+
+
+def test_jax_config_with_grabs_stays_finite_and_normalised(oracle):
+    """scripts/jax_train.py configuration (3+3 agents, RandomFlipTeams|UseFixedWorld|ZeroAgentVelocity) with grab / lock
+    actions: joints snap misaligned bodies round by large angles, which the Newton-step quaternion normalisation must
+    not be used for (it once produced NaN rotations here)."""
+    ref = oracle.RefSim(40, sim_flags=13, rand_seed=5, min_hiders=3, max_hiders=3, min_seekers=3, max_seekers=3, threads=4)
+    ref.init()
+    rng = np.random.default_rng(1)
+    rows = ref.N * ref.A
+    worst = 0.0
+    for t in range(130):
+        ref.tensor("action")[:] = np.stack([rng.integers(0, 11, rows), rng.integers(0, 11, rows), rng.integers(0, 11, rows),
+                                            rng.integers(0, 2, rows), rng.integers(0, 2, rows)], axis=1)
+        ref.step()
+        b, m = ref.bodies()
+        live = m[:, :, 0] >= 0
+        assert np.isfinite(b[live]).all(), f"non-finite body state at step {t}"
+        worst = max(worst, float(np.abs(np.linalg.norm(b[live][:, 3:7], axis=1) - 1.0).max()))
+    assert worst < 1e-3, worst
+    for k in ("self_data", "agent_data", "box_data", "lidar", "reward"):
+        assert np.isfinite(ref.tensor(k)).all(), k
+    ref.close()
