@@ -7,22 +7,22 @@
 // phase costs: measured on MI355X, every sparse phase then takes as long as its worst wave, 3-4x
 // the average one), and a world's columns stay in the CU's L1 / the XCD's L2 from phase to phase.
 //
-// Per-body work runs with SLOT-MAJOR lanes over the workgroup's worlds: item t -> slot = t / wcnt,
-// world = wbeg + t % wcnt, so the lanes of a wave hold the same body slot of consecutive worlds:
-// coalesced dword accesses of world-fastest columns, lanes share the hull type.  The sparse work —
-// convex tests of candidate pairs, body-body manifolds — is compacted into the workgroup's slice of
-// the work lists (wavefront scan + one atomic per list) and processed one lane (or 8) per item.
+// Per-body work runs with SLOT-MAJOR lanes over the workgroup's worlds (the compact list of existing bodies keeps
+// that order), so the lanes of a wave hold the same body slot of consecutive worlds: coalesced dword accesses
+// of world-fastest columns, lanes share the hull type.  The sparse work — convex tests of candidate pairs,
+// body-body manifolds, bodies with wall candidates — is compacted into the workgroup's slice of the work lists
+// (wavefront scan + one LDS atomic per list) and processed by one, two or eight lanes per item.
 //
 // Substep s:
-//   integrate        slot-major   (substep 0; later ones happen at the end of body_vel); ground-plane manifold
-//   detect           8 lanes/world   all-pairs AABB candidates -> per-world lists + work lists
-//   sat              per pair     exact convex test -> manifold workspace
+//   integrate        slot-major      (substep 0; later ones happen at the end of body_vel); ground-plane manifold
+//   detect           8 lanes/world   all-pairs AABB candidates -> per-world lists (slot order) + work lists
+//   sat              2 lanes/pair    exact convex test -> manifold workspace
 //   dd<pos>          8 lanes/world*  joints, then body-body manifolds in (i<j) order   (*worlds that have any)
-//   body_pos         slot-major   ground manifold, the body's wall / extra-plane manifolds; velocity derivation
+//   body_pos         lane/body       ground manifold, the body's wall / extra-plane manifolds; velocity derivation
 //   dd<vel>          8 lanes/world*  body-body velocity pass
-//   body_vel         slot-major   ground + wall velocity pass; integrate for substep s+1
+//   body_vel         lane/body       ground + wall velocity pass; integrate for substep s+1
 // The Gauss-Seidel order and every rounding are the oracle's (joints, body-body in pair order,
-// then per body: ground, walls by static id); candidate lists are unordered and sorted on use.
+// then per body: ground, walls by static id).
 #pragma once
 #include "hs_state.h"
 #include "hs_rays.h"
