@@ -32,6 +32,7 @@ struct ObsShared {
     unsigned long long rayKey[kMaxRays];
     unsigned short pairs[kMaxPairs];                       // ray << 5 | body slot
     int nPairs;
+    float lidarSin[30], lidarCos[30];                      // hs_sincosf of the 30 lidar angles, once per workgroup
 };
 
 HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
@@ -79,6 +80,10 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     const int tid = threadIdx.x;
     const int A = S.A;
     stage_world<NT>(S, w, sh, tid);
+    if (tid < 30) {       // lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent
+        float theta = 2.f * kPi * ((float)tid / 30.f) + kPi / 2.f;
+        hs_sincosf(theta, &sh.lidarSin[tid], &sh.lidarCos[tid]);
+    }
     const int counts = S.counts[w];
     const int teams = S.teams[w];
     const int step = S.curEpisodeStep[w];
@@ -100,8 +105,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         if (k < 30) {
             // lidarSystem: 30 rays in the agent's horizontal plane, t_max 200 (sim.cpp:727-738)
             const V3 right = qrot(rot, {1.f, 0.f, 0.f});
-            float theta = 2.f * kPi * ((float)k / 30.f) + kPi / 2.f;
-            float s, c; hs_sincosf(theta, &s, &c);
+            const float s = sh.lidarSin[k], c = sh.lidarCos[k];
             d = normalize(right * c + fwd * s);
             tmax = 200.f;
         } else {
