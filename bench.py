@@ -90,12 +90,20 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the HIP path is the only execution path")
+    # Rehearsal switch for a one-GPU box: HS_BENCH_REHEARSE=1 maps every rank to GPU 0 and uses gloo for the barrier /
+    # max-reduction (RCCL refuses two ranks on one device).  The driver's runs never set it.
+    rehearse = os.environ.get("HS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     N = args.worlds_per_gpu
     torch.manual_seed(rank)
@@ -135,7 +143,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
