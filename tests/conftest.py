@@ -29,3 +29,14 @@ def hideseek_lib():
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """The HIP library and the headless driver exist before any test imports the package (no-op when up to date)."""
+    import build as hs_build
+    hs_build.build_lib()
+    try:
+        hs_build.build_headless()
+    except Exception:
+        pass
