@@ -33,10 +33,10 @@ HSD float ray_box_local(V3 o, V3 d, V3 e) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) miss = true; continue; }
+        // slab in centre / extent form: entry = -o/d - e/|d|, exit = -o/d + e/|d| (no near/far swap)
         float inv = 1.f / dd[k];
-        float t0 = (-ee[k] - oo[k]) * inv, t1 = (ee[k] - oo[k]) * inv;
-        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
-        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+        float c = (-oo[k]) * inv, r = ee[k] * fabsf(inv);
+        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
     }
     if (miss || tn > tf || tn < 0.f) return -1.f;
     return tn;
@@ -69,9 +69,8 @@ HSD float ray_wall(V3 o, V3 d, V3 inv, V3 e) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) miss = true; continue; }
-        float t0 = (-ee[k] - oo[k]) * ii[k], t1 = (ee[k] - oo[k]) * ii[k];
-        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
-        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+        float c = (-oo[k]) * ii[k], r = ee[k] * fabsf(ii[k]);
+        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
     }
     if (miss || tn > tf || tn < 0.f) return -1.f;
     return tn;
@@ -85,9 +84,8 @@ HSD WallZ ray_wall_z(float oz, float dz, float invz) {
     WallZ z = {-3.0e38f, 3.0e38f, false};
     const float o = oz - 1.25f, e = 1.25f;
     if (dz == 0.f) { z.miss = o < -e || o > e; return z; }
-    float t0 = (-e - o) * invz, t1 = (e - o) * invz;
-    if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
-    z.tn = fmaxf(z.tn, t0); z.tf = fminf(z.tf, t1);
+    float c = (-o) * invz, r = e * fabsf(invz);
+    z.tn = fmaxf(z.tn, c - r); z.tf = fminf(z.tf, c + r);
     return z;
 }
 HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, WallZ z) {
@@ -95,15 +93,13 @@ HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, Wall
     bool miss = z.miss;
     if (d.x == 0.f) { if (ox < -ex || ox > ex) miss = true; }
     else {
-        float t0 = (-ex - ox) * inv.x, t1 = (ex - ox) * inv.x;
-        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
-        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+        float c = (-ox) * inv.x, r = ex * fabsf(inv.x);
+        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
     }
     if (d.y == 0.f) { if (oy < -ey || oy > ey) miss = true; }
     else {
-        float t0 = (-ey - oy) * inv.y, t1 = (ey - oy) * inv.y;
-        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
-        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+        float c = (-oy) * inv.y, r = ey * fabsf(inv.y);
+        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
     }
     tn = fmaxf(tn, z.tn); tf = fminf(tf, z.tf);
     if (miss || tn > tf || tn < 0.f) return -1.f;

@@ -696,10 +696,10 @@ static inline float ray_box_local(V3 o, V3 d, V3 e) {
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ee[3] = {e.x, e.y, e.z};
     for (int k = 0; k < 3; ++k) {
         if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) return -1.f; continue; }
+        // slab in centre / extent form: entry = -o/d - e/|d|, exit = -o/d + e/|d| (no near/far swap)
         float inv = 1.f / dd[k];
-        float t0 = (-ee[k] - oo[k]) * inv, t1 = (ee[k] - oo[k]) * inv;
-        if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
-        tn = fmaxf(tn, t0); tf = fminf(tf, t1);
+        float c = (-oo[k]) * inv, r = ee[k] * fabsf(inv);
+        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
     }
     if (tn > tf || tn < 0.f) return -1.f;
     return tn;
