@@ -220,6 +220,15 @@ HSD V3 obj_inv_inertia(int o) {
     if (o == OBJ_HIDER || o == OBJ_SEEKER) return {0.f, 0.f, 1.5f};
     return {0.f, 0.f, 0.f};
 }
+// 1 / inverse inertia per axis (0 where the inverse is 0): the same IEEE quotients integrate would compute, folded
+// at compile time
+HSD V3 obj_inertia(int o) {
+    if (o == OBJ_CUBE) return {1.f / 0.75f, 1.f / 0.75f, 1.f / 0.75f};
+    if (o == OBJ_BOX) return {1.f / 0.96f, 1.f / 0.088235294f, 1.f / 0.090566038f};
+    if (o == OBJ_RAMP) return {1.f / 0.692307692f, 1.f / 0.9f, 1.f / 0.6f};
+    if (o == OBJ_HIDER || o == OBJ_SEEKER) return {0.f, 0.f, 1.f / 1.5f};
+    return {0.f, 0.f, 0.f};
+}
 HSD V3 obj_half_extents(int o) { return o == OBJ_BOX ? V3{4.f, 0.75f, 1.f} : V3{1.f, 1.f, 1.f}; }
 
 }  // namespace hs

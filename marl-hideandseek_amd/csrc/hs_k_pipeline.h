@@ -119,7 +119,7 @@ HSD void integrate_body(const SimState &S, int w, int slot, int meta, V3 pos, Q 
         pos = pos + lin * h;
         Q qi = qinv(rot);
         V3 wl = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, torque_z});
-        V3 I = {invI.x > 0.f ? 1.f / invI.x : 0.f, invI.y > 0.f ? 1.f / invI.y : 0.f, invI.z > 0.f ? 1.f / invI.z : 0.f};
+        const V3 I = obj_inertia(obj);            // 1 / invI per axis, 0 where invI is 0
         V3 Iw = mulc(I, wl);
         wl = wl + mulc(invI, tl - cross(wl, Iw)) * h;
         ang = qrot(rot, wl);
