@@ -862,7 +862,9 @@ HSD void post_pass(const SimState &S, PostLds &L, int wfirst) {
         }
     }
     __syncthreads();
-    for (int pr = l; wok && pr < 9; pr += G) {      // (seeker, hider) pairs
+    // The seen flag feeds the reward (from episode step 95 on) and the episode result (from 96 on); k_reset overwrites
+    // hiderTeamReward every step, so during the preparation phase the rays would change nothing anyone can read.
+    for (int pr = l; wok && step >= kNumPrepSteps - 1 && pr < 9; pr += G) {      // (seeker, hider) pairs
         const int si = pr / 3, hi_ = pr % 3;
         if (si < cnt_seekers(counts) && hi_ < cnt_hiders(counts)) {
             const int ss = kAgentSlot0 + team_seeker(teams, si), hs_ = kAgentSlot0 + team_hider(teams, hi_);
