@@ -85,7 +85,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
         hipLaunchKernelGGL(hs::k_physics, dim3((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds), dim3(hs::kPhysThreads), 0, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
-    if (stages & 2) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
+    // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
+    if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
     if (stages & 4) launch_observe(s, strm);
     if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));

@@ -28,6 +28,7 @@
 #include "hs_rays.h"
 #include "hs_collide.h"
 #include "hs_solver.h"
+#include "hs_k_reset.h"
 
 namespace hs {
 
@@ -978,6 +979,9 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     }
     phase_post(S, lds.post);
     HS_TICK(8)
+    // resetSystem for the workgroup's worlds (one wave; the level generator diverges per world anyway): step
+    // counter, or a whole new level on the 240th step / on request
+    if (threadIdx.x < S.wcnt) reset_world(S, S.wbeg + threadIdx.x);
 #ifdef HS_PHASE_TIMING
     if (threadIdx.x == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[blockIdx.x * 10 + i] += acc[i];
 #endif

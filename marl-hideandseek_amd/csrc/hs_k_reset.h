@@ -434,9 +434,8 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
     }
 }
 
-__global__ void __launch_bounds__(64) k_reset(SimState S) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= S.N) return;
+// resetSystem (src/sim.cpp:172-200) for one world
+HSD void reset_world(const SimState &S, int w) {
     int level = S.xReset[w];
     const int step = S.curEpisodeStep[w];
     if ((S.flags & FLAG_IGNORE_EPISODE_LENGTH) != FLAG_IGNORE_EPISODE_LENGTH && step == kEpisodeLen - 1) level = 1;
@@ -446,6 +445,14 @@ __global__ void __launch_bounds__(64) k_reset(SimState S) {
         return;
     }
     regenerate_world<false>(S, w, level, nullptr);
+}
+
+// Stand-alone launch: Manager::init (the Init task graph has no physics in front of the reset).  In a step the
+// reset runs at the end of k_physics, by the workgroup that owns the world.
+__global__ void __launch_bounds__(64) k_reset(SimState S) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= S.N) return;
+    reset_world(S, w);
 }
 
 // LoadCheckpoints graph, first node (sim.cpp:1324-1329); the trigger is left at 1 as sim.cpp:963 does.
