@@ -943,6 +943,13 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     if (threadIdx.x < 8) list_len[threadIdx.x] = 0;
     S.counters = list_len;
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
+    const int ngroups = gridDim.x;
+    if (S.stepPar >= 0 && threadIdx.x == 0) {          // clear the next step's half of the finish list
+        const int pn = S.stepPar ^ 1;
+        S.doneList[pn * ngroups + blockIdx.x] = -1;
+        if (blockIdx.x == 0) { S.doneTickets[pn] = 0; S.startedCount[pn] = 0; }
+        __hip_atomic_fetch_add(&S.startedCount[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef HS_PHASE_TIMING
     // development aid: wall-clock ticks (100 MHz) per phase of every workgroup -> S.phaseTicks[workgroup][10]
     long long tk = wall_clock64(); long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -982,10 +989,32 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     // resetSystem for the workgroup's worlds (one wave; the level generator diverges per world anyway): step
     // counter, or a whole new level on the 240th step / on request
     if (threadIdx.x < S.wcnt) reset_world(S, S.wbeg + threadIdx.x);
+    // Publish this workgroup's worlds to k_observe, which runs beside this kernel and takes finished groups in
+    // the order of this list: every wave's stores are drained by the barrier, then one lane releases at agent
+    // scope (the XCDs' L2s are not coherent with each other) and appends the group.
+    if (S.stepPar >= 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int ticket = atomicAdd(&S.doneTickets[S.stepPar], 1);
+            __hip_atomic_store(&S.doneList[S.stepPar * ngroups + ticket], (int)blockIdx.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef HS_PHASE_TIMING
     if (threadIdx.x == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[blockIdx.x * 10 + i] += acc[i];
 #endif
 #undef HS_TICK
+}
+
+// Holds the stream of k_observe back until every workgroup of k_physics has started, i.e. holds a CU: the spinning
+// k_observe workgroups that follow can then never keep a physics workgroup from being placed.  One wave.
+__global__ void __launch_bounds__(64) k_gate(SimState S, int ngroups) {
+    if (threadIdx.x != 0) return;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(&S.startedCount[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ngroups) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    *S.schedErr = 2;
 }
 
 }  // namespace hs

@@ -64,6 +64,13 @@ struct SimState {
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
     int *bodyList;         // [N][17] existing bodies of a workgroup's worlds, compacted once per step (w << 5 | slot)
     int *satList, *wallList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
+    // --- dependency schedule between k_physics and k_observe (hideseek.hip launch_step): workgroup ids of k_physics
+    // in the order they finished, double-buffered by step parity
+    int *doneList;         // [2][groups]  -1 = not finished yet
+    int *doneTickets;      // [2]
+    int *startedCount;     // [2] physics workgroups that have started (k_gate holds k_observe back until all have)
+    int *schedErr;         // [1] set when a consumer gave up waiting (never observed; keeps a bug from hanging the GPU)
+    int stepPar;           // parity of this step, or -1: k_observe does not wait (init, checkpoints, graph replay)
     long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
     int *counters;         // [2][4] list lengths (sat box items, wall bodies, ddw, sat ramp items), double-buffered by substep
                            // parity; set by k_physics to its workgroup's LDS copy
