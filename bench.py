@@ -147,8 +147,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # Roofline position of the dominant kernel.  A step is three kernels: k_physics (persistent: movement /
-    # actions, 4 XPBD substeps, rewards), k_reset, k_observe.  Durations are HIP events on the launch stream
+    # Roofline position of the dominant kernel.  A step is two kernels: k_physics (persistent: movement / actions,
+    # 4 XPBD substeps, rewards, per-step reset) and k_observe; the "reset" stage is the (empty) gap between them.  Durations are HIP events on the launch stream
     # (hs_set_profiling); profiles/ holds the rocprofv3 --kernel-trace --stats summary of this command, whose
     # per-kernel averages agree with them.
     names = {"physics": "k_physics", "reset": "k_reset", "observe": "k_observe"}
