@@ -37,8 +37,8 @@ def algorithmic_bytes(sim, A, kernel):
         per_world = 2 * 56 * D + 16 * S + 2 * 64 + 2 * 20 * A
     elif kernel == "observe":
         per_world = 56 * D + 16 * S + 64 + (1268 * A + 144)
-    else:
-        per_world = 0 * D + 64
+    else:                               # "step": SURVEY §8(d)'s B for the whole step (state r+w once, exports written once)
+        per_world = 2 * 56 * D + 16 * S + 2 * 64 + 2 * 20 * A + (1268 * A + 144 if kernel == "step" else 0)
     return float(per_world.sum()), float(per_world.sum() / n)
 
 
@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1920)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--worlds-per-gpu", type=int, default=WORLDS_PER_GPU)
+    ap.add_argument("--worlds-per-gpu", type=int, default=WORLDS_PER_GPU,
+                    help="16000 = BASELINE configs[1] (default); 16384 = one rank of configs[3] (131072 worlds over 8 GPUs)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -132,7 +133,9 @@ def main():
         torch.cuda.synchronize()
 
     sim.set_profiling(True)
-    kms = {"physics": 0.0, "reset": 0.0, "observe": 0.0}
+    # the kernels a step launches: k_physics (its tail is the per-step reset) and, unless skipped, k_observe
+    skip_obs = bool(args.flags & (1 << 16))
+    kms = {"physics": 0.0} if skip_obs else {"physics": 0.0, "observe": 0.0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -148,10 +151,10 @@ def main():
         dt = float(t.item())
 
     # Roofline position of the dominant kernel.  A step is two kernels: k_physics (persistent: movement / actions,
-    # 4 XPBD substeps, rewards, per-step reset) and k_observe; the "reset" stage is the (empty) gap between them.  Durations are HIP events on the launch stream
+    # 4 XPBD substeps, rewards, per-step reset) and k_observe.  Durations are HIP events on the launch stream
     # (hs_set_profiling); profiles/ holds the rocprofv3 --kernel-trace --stats summary of this command, whose
-    # per-kernel averages agree with them.
-    names = {"physics": "k_physics", "reset": "k_reset", "observe": "k_observe"}
+    # per-kernel averages agree with them.  Only kernels that were launched are listed.
+    names = {"physics": "k_physics", "observe": "k_observe"}
     per_stage = {}
     for n in kms:
         avg_ms = kms[n] / max(args.steps, 1)
@@ -159,19 +162,27 @@ def main():
         ach = total_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_stage[n] = {"kernel": names[n], "avg_ms": avg_ms, "algorithmic_bytes_per_world_step": per_world,
                         "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS}
+        assert 0.0 <= per_stage[n]["frac"] <= 1.0, f"roofline fraction of {n} out of range: {per_stage[n]}"
     dom = max(kms, key=lambda n: kms[n])
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")   # PMC FETCH_SIZE/WRITE_SIZE passes (tools/pmc.sh)
-    if os.path.exists(tpath):
+    # PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh): the newest round's file
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+    if tfiles and N == WORLDS_PER_GPU:
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_step")
+            traffic = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1]))).get(dom, {}).get("hbm_bytes_per_step")
         except Exception:
             traffic = None
+    step_bytes, step_per_world = algorithmic_bytes(sim, A, "physics_only_step" if skip_obs else "step")
+    step_ms = dt / args.steps * 1e3
     roofline = {"bound": "hbm", "kernel": per_stage[dom]["kernel"], "achieved": per_stage[dom]["achieved_GBps"],
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": per_stage[dom]["frac"], "traffic": traffic,
                 "avg_kernel_ms": per_stage[dom]["avg_ms"],
                 "algorithmic_bytes_per_world_step": per_stage[dom]["algorithmic_bytes_per_world_step"],
                 "stages": per_stage,
+                # the whole step against the roofline: SURVEY §8(d)'s B per world-step over the wall time per step
+                "step": {"algorithmic_bytes_per_world_step": step_per_world,
+                         "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+                         "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 "kernel_ms_per_step": {n: kms[n] / max(args.steps, 1) for n in kms}}
 
     if rank == 0:
@@ -189,6 +200,13 @@ def main():
                        "worlds_per_gpu": N, "total_worlds": total_worlds, "agents_per_world": A,
                        "sharding": "contiguous world ranges per rank, no collective on the step path"},
             "agent_steps_per_sec": total_worlds * A * args.steps / dt,
+            # which part of the 240-step episode the timed window covers (every world is in lock-step): steps < 95
+            # are the preparation phase (seekers frozen, no reward rays), every 240th step regenerates all levels
+            "episode_steps_covered": {"first": args.warmup % 240, "count": args.steps,
+                                      "level_regenerations": (args.warmup % 240 + args.steps) // 240,
+                                      "note": "a window inside [0, 95) is preparation phase only"
+                                      if args.warmup % 240 + args.steps <= 95 else "covers all phases of an episode"
+                                      if args.steps >= 240 else "partial episode"},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world_size == 1:

@@ -134,6 +134,13 @@ void hs_destroy(hs_sim *sim);
 int32_t hs_init(hs_sim *sim);
 /* Manager::step (src/mgr.cpp:883-903): runs the Step task graph once (sim.cpp:1307-1313); blocking. */
 int32_t hs_step(hs_sim *sim);
+/* The two halves of hs_step, for a front-end that owns several handles (one per GPU of the node): every
+ * handle has its own HIP stream; hs_step_begin orders that stream after the work already queued on the device's
+ * legacy default stream (where torch writes `action`), enqueues the step and returns; hs_step_end waits for it and
+ * reports device-side failures (hs_get_device_status).  hs_step == hs_step_begin + hs_step_end.  The reference is
+ * single-GPU (src/mgr.hpp:18); these replace the executor's run() for the sharded case. */
+int32_t hs_step_begin(hs_sim *sim);
+int32_t hs_step_end(hs_sim *sim);
 /* Manager::gpuJAXStep / CUDAImpl::gpuStreamStep (src/mgr.cpp:379-398, 1006-1022): enqueue one step on a
  * caller-supplied hipStream_t (passed as void*) without synchronising. */
 int32_t hs_step_async(hs_sim *sim, void *hip_stream);
@@ -171,6 +178,45 @@ int32_t hs_jax_init(hs_sim *sim, void *hip_stream, void **buffers);
 int32_t hs_jax_step(hs_sim *sim, void *hip_stream, void **buffers);
 int32_t hs_jax_save_checkpoints(hs_sim *sim, void *hip_stream, void **buffers);
 int32_t hs_jax_load_checkpoints(hs_sim *sim, void *hip_stream, void **buffers);
+
+/* Manager::trainInterface (src/mgr.cpp:1338-1375): the names and roles under which `sim.jax()` hands the exported
+ * tensors to the learner, in the reference's order (which is also the buffer order of hs_jax_step).  `export_id` is
+ * an HS_EXPORT_* value, or -1 for the empty simCtrl tensor (mgr.cpp:1333-1336).  Returns the number of entries and
+ * points *entries at a static table. */
+enum {
+    HS_ROLE_ACTION = 0,        /* TrainInterface inputs.actions */
+    HS_ROLE_RESET = 1,         /* inputs.resets */
+    HS_ROLE_SIM_CTRL = 2,      /* inputs.simCtrl (empty) */
+    HS_ROLE_PBT_INPUT = 3,     /* inputs.pbt */
+    HS_ROLE_OBSERVATION = 4,   /* outputs.observations */
+    HS_ROLE_REWARD = 5,        /* outputs.rewards */
+    HS_ROLE_DONE = 6,          /* outputs.dones */
+    HS_ROLE_PBT_OUTPUT = 7,    /* outputs.pbt */
+    HS_ROLE_CHECKPOINT = 8     /* TrainCheckpointingInterface.checkpointData */
+};
+typedef struct hs_iface_entry {
+    const char *name;
+    int32_t role;
+    int32_t export_id;
+} hs_iface_entry;
+int32_t hs_train_interface(const hs_iface_entry **entries);
+
+/* Device-side conditions the reference has no channel for (it asserts or aborts).
+ *   dropped_dd_pairs / dropped_static_pairs: broadphase candidate pairs beyond the per-world capacities (16 body-body,
+ *     24 body-static per substep) that were discarded — the oracle discards the same ones, so parity cannot see it.
+ *     Sticky totals since hs_create.  hs_step still returns HS_OK; hs_last_error() carries a warning.
+ *   sched_error: non-zero when a bounded device-side wait expired (HS_OVERLAP=1 schedule); the step that saw it
+ *     returns HS_ERR_HIP, and so does the next call of an asynchronous entry point.
+ *   graphs_in_use: 1 when HS_GRAPH=1 took effect and steps are replayed as HIP graphs. */
+typedef struct hs_device_status {
+    int64_t dropped_dd_pairs;
+    int64_t dropped_static_pairs;
+    int32_t sched_error;
+    int32_t graphs_in_use;
+} hs_device_status;
+int32_t hs_get_device_status(hs_sim *sim, hs_device_status *out);
+/* Test hook: plants `code` in the device-side sched_error word as an expired wait would. */
+int32_t hs_debug_inject_sched_error(hs_sim *sim, int32_t code);
 
 /* maxAgentsPerWorld (src/mgr.cpp:684). */
 int32_t hs_agents_per_world(const hs_sim *sim);

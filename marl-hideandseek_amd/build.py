@@ -18,24 +18,33 @@ def sources():
         os.path.join(os.path.dirname(HERE), "include", "hideseek.h")]
 
 
-def up_to_date():
-    if not os.path.exists(LIB):
+def up_to_date(lib=LIB):
+    if not os.path.exists(lib):
         return False
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return all(os.path.getmtime(s) <= t for s in sources())
 
 
-def build_lib(force=False, verbose=False):
-    if not force and up_to_date():
-        return LIB
+def build_lib(force=False, verbose=False, out=LIB, defines=()):
+    if not force and up_to_date(out):
+        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libhideseek.so (there is no CPU fallback)")
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + [
-        "-o", LIB, os.path.join(CSRC, "hideseek.hip")]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-D" + d for d in defines] + (
+        ["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-o", out, os.path.join(CSRC, "hideseek.hip")]
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return out
+
+
+# Test-only build with tiny broadphase capacities, so that the overflow counters of hs_get_device_status can be seen
+# to count (tests/test_gpu_status.py loads it through HS_LIB_PATH in a child process).
+SMALLCAP_LIB = os.path.join(HERE, "lib", "libhideseek_smallcap.so")
+
+
+def build_smallcap(force=False):
+    return build_lib(force=force, out=SMALLCAP_LIB, defines=("HS_MAX_DD_CAND=1", "HS_MAX_S_CAND=1"))
 
 
 def build_headless():
@@ -52,3 +61,4 @@ def build_headless():
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
     print(build_headless())
+    print(build_smallcap(force="--force" in sys.argv))

@@ -47,8 +47,13 @@ struct hs_sim {
     int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
     hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-    bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower now that a step is three launches)
-    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
+    bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower than two direct launches)
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};     // physics, observe
+    hipStream_t stream = nullptr;          // this handle's own stream: hs_init / hs_step / checkpoints run here
+    hipEvent_t evIn = nullptr;             // orders `stream` after the device's legacy default stream (torch's writes to `action`)
+    bool step_open = false;                // hs_step_begin without its hs_step_end
+    int *host_flag = nullptr;              // pinned, device-visible: set by a kernel when it bumps S.status (rare)
+    int status_cache[4] = {0, 0, 0, 0};    // last copy of S.status
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -132,20 +137,23 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     return HS_OK;
 }
 
-// Optional (HS_GRAPH=1): the step as three HIP graphs (physics, reset, observe), captured once on a private
-// stream (the legacy stream cannot be captured) and replayed on the caller's stream; the profiling events stay
-// ordinary stream events between the graph launches.  It paid off while physics was ~40 launches per step;
-// with the persistent physics kernel a step is three launches and the direct launches are faster.
+// Optional (HS_GRAPH=1): the step as two HIP graphs (physics, observe), captured once on a private stream (the
+// legacy stream cannot be captured) and replayed on the caller's stream; the profiling events stay ordinary stream
+// events between the graph launches.  It paid off while physics was ~40 launches per step; with the persistent
+// physics kernel a step is two launches and the direct launches are faster.  When capture or instantiation fails
+// the handle falls back to direct launches and hs_get_device_status reports graphs_in_use = 0.
 int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false) {
     if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling, 7, true, host_joins);
+    const bool skip_obs = (s->S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
+    const int ngraphs = skip_obs ? 1 : 2;
     if (!s->graph_exec[0]) {
         hipStream_t cap = nullptr;
         HS_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
         bool ok = true;
-        for (int g = 0; g < 3 && ok; ++g) {
+        for (int g = 0; g < ngraphs && ok; ++g) {
             hipGraph_t gr = nullptr;
             ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) ok = launch_step_eager(s, cap, false, false, 1 << g) == HS_OK;
+            if (ok) ok = launch_step_eager(s, cap, false, false, g == 0 ? 1 : 4) == HS_OK;
             if (hipStreamEndCapture(cap, &gr) != hipSuccess) ok = false;
             if (ok) ok = hipGraphInstantiate(&s->graph_exec[g], gr, nullptr, nullptr, 0) == hipSuccess;
             if (gr) hipGraphDestroy(gr);
@@ -158,11 +166,24 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false
         }
     }
     const bool prof = s->profiling;
-    for (int g = 0; g < 3; ++g) {
-        if (prof) HS_HIP(hipEventRecord(s->ev[g], strm));
-        HS_HIP(hipGraphLaunch(s->graph_exec[g], strm));
-    }
+    if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
+    HS_HIP(hipGraphLaunch(s->graph_exec[0], strm));
+    if (prof) { HS_HIP(hipEventRecord(s->ev[1], strm)); HS_HIP(hipEventRecord(s->ev[2], strm)); }
+    if (!skip_obs) HS_HIP(hipGraphLaunch(s->graph_exec[1], strm));
     if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
+    return HS_OK;
+}
+
+// Device-side conditions (include/hideseek.h hs_device_status).  The kernels bump S.status and raise the pinned
+// host flag only when something happened, so the check after a step is one host-memory read.
+int poll_status(hs_sim *s) {
+    if (!s->host_flag || !*(volatile int *)s->host_flag) return HS_OK;
+    HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
+    if (s->status_cache[2] != 0)
+        return fail(HS_ERR_HIP, "device-side wait expired (sched_error " + std::to_string(s->status_cache[2]) +
+                                "): the observations of this step are incomplete");
+    g_err = "warning: broadphase candidate pairs beyond the per-world capacity were dropped (" +
+            std::to_string(s->status_cache[0]) + " body-body, " + std::to_string(s->status_cache[1]) + " body-static so far)";
     return HS_OK;
 }
 
@@ -226,10 +247,14 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.bodyList, N * D); HS_ALLOC(S.ddwList, 2 * N);
     { const size_t G = (N + hs::kPhysWorlds - 1) / hs::kPhysWorlds;
       if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
-      HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); HS_ALLOC(S.schedErr, 1); }
+      HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
     S.stepPar = -1;
     HS_ALLOC(S.phaseTicks, 10 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
+    HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
+    if (hipHostMalloc((void **)&s->host_flag, 64, hipHostMallocMapped) != hipSuccess) { s->host_flag = nullptr; hs_destroy(s); return fail(HS_ERR_HIP, "hipHostMalloc failed"); }
+    *s->host_flag = 0;
+    if (hipHostGetDevicePointer((void **)&S.hostFlag, s->host_flag, 0) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipHostGetDevicePointer failed"); }
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
         std::vector<int32_t> ones(N, 1), neg(AG * N, -1);
@@ -245,7 +270,9 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HS_OVERLAP")) s->overlap = atoi(e) != 0;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->gpu_id) == hipSuccess) s->num_cus = prop.multiProcessorCount; }
-    if (hipStreamCreateWithFlags(&s->obs_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->obs_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
     S.wbeg = 0; S.wcnt = (int)N;
@@ -285,38 +312,73 @@ void hs_destroy(hs_sim *s) {
     if (s->evFork) hipEventDestroy(s->evFork);
     if (s->evJoin) hipEventDestroy(s->evJoin);
     if (s->obs_stream) hipStreamDestroy(s->obs_stream);
+    if (s->evIn) hipEventDestroy(s->evIn);
+    if (s->stream) hipStreamDestroy(s->stream);
+    if (s->host_flag) hipHostFree(s->host_flag);
     for (auto &e : s->graph_exec) if (e) hipGraphExecDestroy(e);
     delete s;
 }
 
 int32_t hs_agents_per_world(const hs_sim *s) { return s ? s->A : 0; }
 
+namespace {
+// The handle's own stream starts after everything already queued on the device's legacy default stream: that is
+// where torch (and scripts/benchmark.py:82-84) writes `action` / `reset` between steps.
+int order_after_default_stream(hs_sim *s) {
+    HS_HIP(hipEventRecord(s->evIn, nullptr));
+    HS_HIP(hipStreamWaitEvent(s->stream, s->evIn, 0));
+    return HS_OK;
+}
+}  // namespace
+
 int32_t hs_init(hs_sim *s) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int rc = launch_step(s, nullptr, true);
+    int rc = order_after_default_stream(s);
+    if (rc == HS_OK) rc = launch_step(s, s->stream, true);
     if (rc != HS_OK) return rc;
-    HS_HIP(hipStreamSynchronize(nullptr));
+    HS_HIP(hipStreamSynchronize(s->stream));
     s->initialised = true;
     return HS_OK;
 }
 
-int32_t hs_step(hs_sim *s) {
+int32_t hs_step_begin(hs_sim *s) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    if (s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_step_begin: the previous step was not ended");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int rc = launch_step(s, nullptr, false, true);
+    int rc = order_after_default_stream(s);
+    if (rc == HS_OK) rc = launch_step(s, s->stream, false, true);
     if (rc != HS_OK) return rc;
-    HS_HIP(hipStreamSynchronize(nullptr));
-    if (s->overlapped_last) HS_HIP(hipStreamSynchronize(s->obs_stream));
-    if (s->profiling)
-        for (int i = 0; i < 3; ++i) HS_HIP(hipEventElapsedTime(&s->last_ms[i], s->ev[i], s->ev[i + 1]));
+    s->step_open = true;
     return HS_OK;
+}
+
+int32_t hs_step_end(hs_sim *s) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    if (!s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_step_end without hs_step_begin");
+    s->step_open = false;
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipStreamSynchronize(s->stream));
+    if (s->overlapped_last) HS_HIP(hipStreamSynchronize(s->obs_stream));
+    if (s->profiling) {
+        for (int i = 0; i < 3; ++i) HS_HIP(hipEventElapsedTime(&s->last_ms[i], s->ev[i], s->ev[i + 1]));
+        // under the dependency schedule ev[3] is recorded on the observation stream: ev[2]..ev[3] is then the span
+        // from the end of k_physics' launch slot to the end of k_observe, not a kernel duration
+        if (s->overlapped_last) s->last_ms[2] = -1.f;
+    }
+    return poll_status(s);
+}
+
+int32_t hs_step(hs_sim *s) {
+    int rc = hs_step_begin(s);
+    return rc != HS_OK ? rc : hs_step_end(s);
 }
 
 int32_t hs_step_async(hs_sim *s, void *hip_stream) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    return launch_step(s, (hipStream_t)hip_stream, false);
+    int rc = poll_status(s);               // a failure of an earlier asynchronous step surfaces here
+    return rc != HS_OK ? rc : launch_step(s, (hipStream_t)hip_stream, false);
 }
 
 int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
@@ -382,17 +444,19 @@ int set_ckpt_trigger(hs_sim *s, int32_t world) {
 int32_t hs_save_checkpoints(hs_sim *s) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int rc = launch_save_ckpts(s, nullptr);
+    int rc = order_after_default_stream(s);
+    if (rc == HS_OK) rc = launch_save_ckpts(s, s->stream);
     if (rc != HS_OK) return rc;
-    HS_HIP(hipStreamSynchronize(nullptr));
+    HS_HIP(hipStreamSynchronize(s->stream));
     return HS_OK;
 }
 int32_t hs_load_checkpoints(hs_sim *s) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int rc = launch_load_ckpts(s, nullptr);
+    int rc = order_after_default_stream(s);
+    if (rc == HS_OK) rc = launch_load_ckpts(s, s->stream);
     if (rc != HS_OK) return rc;
-    HS_HIP(hipStreamSynchronize(nullptr));
+    HS_HIP(hipStreamSynchronize(s->stream));
     return HS_OK;
 }
 int32_t hs_save_checkpoint(hs_sim *s, int32_t world) {
@@ -449,7 +513,8 @@ int32_t hs_jax_step(hs_sim *s, void *hip_stream, void **buffers) {
     hipStream_t strm = (hipStream_t)hip_stream;
     const hs::SimState &S = s->S;
     const size_t N = (size_t)S.N, R = N * s->A;
-    int rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
+    int rc = poll_status(s);               // a failure of an earlier asynchronous step surfaces here
+    if (rc == HS_OK) rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
     if (rc == HS_OK) rc = copy_dd(S.xReset, *buffers++, N * 4, strm);
     if (rc == HS_OK) rc = copy_dd(S.xPolicy, *buffers++, R * 4, strm);
     if (rc == HS_OK) rc = launch_step(s, strm, false);
@@ -561,6 +626,53 @@ int32_t hs_debug_calibrate(int64_t bytes) {
 // binding keeps the DLManagedTensor records alive, so there is nothing to free (and nothing here may call
 // back into an interpreter that is shutting down).
 void hs_dlpack_noop_deleter(void *) {}
+
+int32_t hs_train_interface(const hs_iface_entry **entries) {
+    // Manager::trainInterface (mgr.cpp:1338-1375), in its order
+    static const hs_iface_entry table[] = {
+        {"actions", HS_ROLE_ACTION, HS_EXPORT_ACTION},
+        {"resets", HS_ROLE_RESET, HS_EXPORT_RESET},
+        {"sim_ctrl", HS_ROLE_SIM_CTRL, -1},
+        {"policy_assignments", HS_ROLE_PBT_INPUT, HS_EXPORT_AGENT_POLICY},
+        {"prep_counter", HS_ROLE_OBSERVATION, HS_EXPORT_PREP_COUNTER},
+        {"self_data", HS_ROLE_OBSERVATION, HS_EXPORT_SELF_OBS},
+        {"self_type", HS_ROLE_OBSERVATION, HS_EXPORT_SELF_TYPE},
+        {"self_mask", HS_ROLE_OBSERVATION, HS_EXPORT_SELF_MASK},
+        {"self_lidar", HS_ROLE_OBSERVATION, HS_EXPORT_LIDAR},
+        {"agent_data", HS_ROLE_OBSERVATION, HS_EXPORT_AGENT_OBS},
+        {"box_data", HS_ROLE_OBSERVATION, HS_EXPORT_BOX_OBS},
+        {"ramp_data", HS_ROLE_OBSERVATION, HS_EXPORT_RAMP_OBS},
+        {"vis_agents_mask", HS_ROLE_OBSERVATION, HS_EXPORT_AGENT_VIS_MASKS},
+        {"vis_boxes_mask", HS_ROLE_OBSERVATION, HS_EXPORT_BOX_VIS_MASKS},
+        {"vis_ramps_mask", HS_ROLE_OBSERVATION, HS_EXPORT_RAMP_VIS_MASKS},
+        {"rewards", HS_ROLE_REWARD, HS_EXPORT_REWARD},
+        {"dones", HS_ROLE_DONE, HS_EXPORT_DONE},
+        {"episode_results", HS_ROLE_PBT_OUTPUT, HS_EXPORT_EPISODE_RESULT},
+        {"checkpoint_data", HS_ROLE_CHECKPOINT, HS_EXPORT_CHECKPOINT},
+    };
+    if (entries) *entries = table;
+    return (int32_t)(sizeof(table) / sizeof(table[0]));
+}
+
+int32_t hs_get_device_status(hs_sim *s, hs_device_status *out) {
+    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
+    out->dropped_dd_pairs = s->status_cache[0];
+    out->dropped_static_pairs = s->status_cache[1];
+    out->sched_error = s->status_cache[2];
+    out->graphs_in_use = (s->use_graph && s->graph_exec[0]) ? 1 : 0;
+    return HS_OK;
+}
+
+int32_t hs_debug_inject_sched_error(hs_sim *s, int32_t code) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipMemcpy(s->S.status + 2, &code, sizeof(code), hipMemcpyHostToDevice));
+    *s->host_flag = code != 0 ? 1 : *s->host_flag;
+    return HS_OK;
+}
 
 int32_t hs_set_profiling(hs_sim *s, int32_t enabled) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");

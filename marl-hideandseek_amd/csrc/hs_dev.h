@@ -31,9 +31,17 @@ constexpr float kSubstepH = (1.f / 30.f) / 4.f;
 constexpr float kInvSubstepH = 120.f;
 constexpr float kGravityZ = -9.8f;
 constexpr float kMaxDepenVel = 3.f;
-constexpr int kMaxDDCand = 16;
+// Candidate-pair capacities per world per substep (DESIGN.md "Engine decisions"); -DHS_MAX_DD_CAND / -DHS_MAX_S_CAND
+// shrink them for the overflow test (tests/test_gpu_status.py), nothing else overrides them.
+#ifndef HS_MAX_DD_CAND
+#define HS_MAX_DD_CAND 16
+#endif
+#ifndef HS_MAX_S_CAND
+#define HS_MAX_S_CAND 24
+#endif
+constexpr int kMaxDDCand = HS_MAX_DD_CAND;
 constexpr int kGrabWords = 15;      // grab-joint record: r2 3, attach2 4, separation 1, r1 3, attach1 4
-constexpr int kMaxSCand = 24;
+constexpr int kMaxSCand = HS_MAX_S_CAND;
 constexpr float kCosFovHalf = 0.382683426f;
 constexpr float kPi = 3.14159265358979323846f;
 

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
                 if (g >= 0) break;
                 __builtin_amdgcn_s_sleep(32);
             }
-            if (g < 0) *S.schedErr = 1;
+            if (g < 0) { S.status[2] = 1; *S.hostFlag = 1; }
             sh_group = g;
         }
         __syncthreads();

@@ -303,6 +303,11 @@ HSD void detect_pass(const SimState &S, DetectLds &L, int wfirst, int NS, int pa
         add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
+        if (add[jb] != cdd || asc[jb] != csc) {      // beyond the capacity: dropped (as the oracle does), and counted
+            if (add[jb] != cdd) atomicAdd(&S.status[0], cdd - add[jb]);
+            if (asc[jb] != csc) atomicAdd(&S.status[1], csc - asc[jb]);
+            *S.hostFlag = 1;
+        }
     }
     // ---- reserve space in the work lists: wave scans, workgroup scan, one atomic per list.
     // Convex-test items that involve a ramp (wedge hull) are kept apart from the box-only ones — they go
@@ -1014,7 +1019,7 @@ __global__ void __launch_bounds__(64) k_gate(SimState S, int ngroups) {
         if (__hip_atomic_load(&S.startedCount[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ngroups) return;
         __builtin_amdgcn_s_sleep(8);
     }
-    *S.schedErr = 2;
+    S.status[2] = 2; *S.hostFlag = 1;
 }
 
 }  // namespace hs

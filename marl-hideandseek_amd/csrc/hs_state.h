@@ -69,7 +69,9 @@ struct SimState {
     int *doneList;         // [2][groups]  -1 = not finished yet
     int *doneTickets;      // [2]
     int *startedCount;     // [2] physics workgroups that have started (k_gate holds k_observe back until all have)
-    int *schedErr;         // [1] set when a consumer gave up waiting (never observed; keeps a bug from hanging the GPU)
+    int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, sched error, -
+                           // (include/hideseek.h hs_device_status); bumped only when something happens
+    int *hostFlag;         // pinned host word (device-visible): set to 1 together with any change of status
     int stepPar;           // parity of this step, or -1: k_observe does not wait (init, checkpoints, graph replay)
     long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
     int *counters;         // [2][4] list lengths (sat box items, wall bodies, ddw, sat ramp items), double-buffered by substep

@@ -11,17 +11,19 @@ There is no CPU execution path: if the HIP library or a GPU is missing the const
 import atexit
 import ctypes as C
 import enum
-import os
 import weakref
 
-__all__ = ["HideAndSeekSimulator", "SimFlags", "madrona", "Tensor", "library_path"]
+from . import _native
+from . import madrona
+from ._native import HsConfig as _HsConfig, HsTensorDesc as _HsTensorDesc, check as _check, load as _load
+from .madrona import Tensor
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("HS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libhideseek.so")
+__all__ = ["HideAndSeekSimulator", "ShardedSimulator", "SimFlags", "madrona", "Tensor", "library_path",
+           "train_interface"]
 
 
 def library_path():
-    return _LIB_PATH
+    return _native.LIB_PATH
 
 
 class SimFlags(enum.IntFlag):
@@ -35,177 +37,31 @@ class SimFlags(enum.IntFlag):
     ExtSkipObservations = 1 << 16
 
 
-class _ExecMode(enum.IntEnum):
-    CPU = 0
-    CUDA = 1   # the reference's name for "GPU"; here it means HIP on gfx950
-
-
-class _HsConfig(C.Structure):
-    _fields_ = [("exec_mode", C.c_int32), ("gpu_id", C.c_int32), ("num_worlds", C.c_int32),
-                ("sim_flags", C.c_uint32), ("rand_seed", C.c_uint32),
-                ("min_hiders", C.c_int32), ("max_hiders", C.c_int32),
-                ("min_seekers", C.c_int32), ("max_seekers", C.c_int32),
-                ("num_pbt_policies", C.c_int32), ("enable_batch_renderer", C.c_int32),
-                ("batch_render_width", C.c_int32), ("batch_render_height", C.c_int32),
-                ("world_offset", C.c_int32)]
-
-
-class _HsTensorDesc(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
-                ("dims", C.c_int64 * 4), ("gpu_id", C.c_int32)]
-
-
-# ---- DLPack (dlpack.h v0.8 ABI) built with ctypes: no torch types cross the C ABI ----
-class _DLDevice(C.Structure):
-    _fields_ = [("device_type", C.c_int32), ("device_id", C.c_int32)]
-
-
-class _DLDataType(C.Structure):
-    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
-
-
-class _DLTensor(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int32), ("dtype", _DLDataType),
-                ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
-
-
-class _DLManagedTensor(C.Structure):
-    pass
-
-
-_DLDeleter = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
-_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DLDeleter)]
-
-_kDLROCM = 10
-_DTYPES = {0: (0, 32, "int32"), 1: (2, 32, "float32"), 2: (1, 8, "uint8")}   # id -> (code, bits, name)
-
-# DLManagedTensor records handed out so far.  They are tiny, non-owning and must outlive every consumer
-# (torch may run the deleter while the interpreter is shutting down, so the deleter is a C no-op in
-# libhideseek and the records are simply kept for the life of the process).
-_live_exports = []
-
-
-class Tensor:
-    """Counterpart of madrona::py::Tensor (src/mgr.cpp:824-842): a non-owning view."""
-
-    def __init__(self, owner, desc):
-        self._owner = owner            # keeps the simulator (and so the memory) alive
-        self.ptr = desc.ptr
-        self.dtype_id = desc.dtype
-        self.shape = tuple(int(desc.dims[i]) for i in range(desc.ndim))
-        self.gpu_id = desc.gpu_id
-
-    @property
-    def dtype(self):
-        return _DTYPES[self.dtype_id][2]
-
-    def __dlpack_device__(self):
-        return (_kDLROCM, self.gpu_id)
-
-    def __dlpack__(self, stream=None, **_):
-        code, bits, _name = _DTYPES[self.dtype_id]
-        nd = len(self.shape)
-        shape = (C.c_int64 * nd)(*self.shape)
-        mt = _DLManagedTensor()
-        mt.dl_tensor.data = self.ptr
-        mt.dl_tensor.device = _DLDevice(_kDLROCM, self.gpu_id)
-        mt.dl_tensor.ndim = nd
-        mt.dl_tensor.dtype = _DLDataType(code, bits, 1)
-        mt.dl_tensor.shape = C.cast(shape, C.POINTER(C.c_int64))
-        mt.dl_tensor.strides = None
-        mt.dl_tensor.byte_offset = 0
-        mt.manager_ctx = None
-        mt.deleter = C.cast(_load().hs_dlpack_noop_deleter, _DLDeleter)
-        _live_exports.append((mt, shape))
-        new_capsule = C.pythonapi.PyCapsule_New
-        new_capsule.restype = C.py_object
-        new_capsule.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
-        return new_capsule(C.addressof(mt), b"dltensor", None)
-
-    def to_torch(self):
-        import torch
-        t = torch.from_dlpack(self)
-        return t
-
-    def to_jax(self):
-        import jax.dlpack
-        return jax.dlpack.from_dlpack(self)
-
-    def __repr__(self):
-        return f"Tensor(shape={self.shape}, dtype={self.dtype}, gpu={self.gpu_id}, ptr=0x{self.ptr or 0:x})"
-
-
-_lib = None
-
-
-def _load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    # PyTorch-ROCm wheels bundle their own HIP runtime (same SONAME as the system one).  If libhideseek pulled the
-    # system copy in first, a later `import torch` would find "No HIP GPUs" — and the reference's scripts import
-    # gpu_hideseek before torch (scripts/benchmark.py:1-2).  Loading torch first makes both share one runtime.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
-    if not os.path.exists(_LIB_PATH):
-        raise ImportError(
-            f"{_LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
-            "(hipcc --offload-arch=gfx950). gpu_hideseek has no CPU fallback.")
-    L = C.CDLL(_LIB_PATH)
-    L.hs_create.argtypes = [C.POINTER(_HsConfig), C.POINTER(C.c_void_p)]
-    L.hs_create.restype = C.c_int32
-    L.hs_destroy.argtypes = [C.c_void_p]
-    L.hs_destroy.restype = None
-    for n in ("hs_init", "hs_step", "hs_save_checkpoints", "hs_load_checkpoints"):
-        getattr(L, n).argtypes = [C.c_void_p]
-        getattr(L, n).restype = C.c_int32
-    for n in ("hs_save_checkpoint", "hs_load_checkpoint"):
-        getattr(L, n).argtypes = [C.c_void_p, C.c_int32]
-        getattr(L, n).restype = C.c_int32
-    for n in ("hs_jax_init", "hs_jax_step", "hs_jax_save_checkpoints", "hs_jax_load_checkpoints"):
-        getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
-        getattr(L, n).restype = C.c_int32
-    L.hs_step_async.argtypes = [C.c_void_p, C.c_void_p]
-    L.hs_step_async.restype = C.c_int32
-    L.hs_get_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_HsTensorDesc)]
-    L.hs_get_tensor.restype = C.c_int32
-    L.hs_trigger_reset.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
-    L.hs_trigger_reset.restype = C.c_int32
-    L.hs_set_action.argtypes = [C.c_void_p] + [C.c_int32] * 6
-    L.hs_set_action.restype = C.c_int32
-    L.hs_agents_per_world.argtypes = [C.c_void_p]
-    L.hs_agents_per_world.restype = C.c_int32
-    L.hs_debug_dump_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.hs_debug_dump_bodies.restype = C.c_int32
-    L.hs_debug_dump_walls.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.hs_debug_dump_walls.restype = C.c_int32
-    L.hs_set_profiling.argtypes = [C.c_void_p, C.c_int32]
-    L.hs_set_profiling.restype = C.c_int32
-    L.hs_last_step_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 3)]
-    L.hs_last_step_kernel_ms.restype = C.c_int32
-    L.hs_last_error.restype = C.c_char_p
-    L.hs_version.restype = C.c_char_p
-    _lib = L
-    return L
-
-
-def _check(rc):
-    if rc != 0:
-        msg = _load().hs_last_error().decode()
-        if rc == 1:
-            raise ValueError(msg)
-        if rc == 3:
-            raise NotImplementedError(msg)
-        raise RuntimeError(f"libhideseek error {rc}: {msg}")
-
-
 # ExportID (src/sim.hpp:45-68) + renderer outputs
 _EXPORTS = dict(reset=0, prep_counter=1, action=2, self_data=3, self_type=4, self_mask=5, agent_data=6,
                 box_data=7, ramp_data=8, visible_agents_mask=9, visible_boxes_mask=10, visible_ramps_mask=11,
                 lidar=12, seed=13, reward=14, done=15, global_positions=16, policy_assignments=17,
                 episode_result=18, ckpt_ctrl=19, ckpt=20, depth=21, rgb=22)
+
+
+_EXPORT_NAMES = {v: k for k, v in _EXPORTS.items()}
+_ROLES = {0: "actions", 1: "resets", 2: "sim_ctrl", 3: "pbt_inputs", 4: "observations", 5: "rewards", 6: "dones",
+          7: "pbt_outputs", 8: "checkpoint_data"}
+
+
+def train_interface():
+    """Manager::trainInterface (src/mgr.cpp:1338-1375) as the library reports it (hs_train_interface): a list of
+    (name, role, getter) in the reference's order, e.g. ("self_lidar", "observations", "lidar_tensor").  The getter
+    is None for the empty simCtrl tensor (mgr.cpp:1333-1336)."""
+    L = _load()
+    tab = C.POINTER(_native.HsIfaceEntry)()
+    n = L.hs_train_interface(C.byref(tab))
+    out = []
+    for i in range(n):
+        e = tab[i]
+        getter = None if e.export_id < 0 else _EXPORT_NAMES[e.export_id] + "_tensor"
+        out.append((e.name.decode(), _ROLES[e.role], getter))
+    return out
 
 
 _live_sims = weakref.WeakSet()
@@ -233,13 +89,18 @@ class HideAndSeekSimulator:
         _check(L.hs_create(C.byref(cfg), C.byref(self._h)))
         self._L = L
         self.num_worlds = int(num_worlds)
+        self.world_offset = int(world_offset)
+        self.gpu_id = int(gpu_id)
         self.agents_per_world = L.hs_agents_per_world(self._h)
+        self._tensors = {}
         _live_sims.add(self)
 
     def close(self):
-        """Manager::~Manager (mgr.cpp:848-859).  Tensor views must not be used afterwards."""
+        """Manager::~Manager (mgr.cpp:848-859).  Tensor views — and torch / jax arrays made from them — must not be
+        used afterwards: they are non-owning (madrona.Tensor)."""
         h = getattr(self, "_h", None)
         if h:
+            self._tensors = {}
             self._L.hs_destroy(h)
             self._h = None
 
@@ -252,14 +113,25 @@ class HideAndSeekSimulator:
     def step(self):
         _check(self._L.hs_step(self._h))
 
+    def step_begin(self):
+        """Enqueue one step on this handle's own stream and return (hs_step_begin); pair with step_end()."""
+        _check(self._L.hs_step_begin(self._h))
+
+    def step_end(self):
+        """Wait for the step started by step_begin() and report device-side failures (hs_step_end)."""
+        _check(self._L.hs_step_end(self._h))
+
     def step_async(self, hip_stream):
         """Enqueue one step on a caller-owned HIP stream (Manager::gpuJAXStep, mgr.cpp:1006-1022)."""
         _check(self._L.hs_step_async(self._h, C.c_void_p(int(hip_stream))))
 
     def _tensor(self, name):
-        d = _HsTensorDesc()
-        _check(self._L.hs_get_tensor(self._h, _EXPORTS[name], C.byref(d)))
-        return Tensor(self, d)
+        t = self._tensors.get(name)
+        if t is None:
+            d = _HsTensorDesc()
+            _check(self._L.hs_get_tensor(self._h, _EXPORTS[name], C.byref(d)))
+            t = self._tensors[name] = Tensor(weakref.proxy(self), d)
+        return t
 
     # the 21 getters of bindings.cpp:76-96
     def reset_tensor(self): return self._tensor("reset")
@@ -339,12 +211,39 @@ class HideAndSeekSimulator:
             raise ValueError("stream_load_checkpoints takes ckpt_ctrl, ckpts, 11 observation buffers")
         self._stream_call(self._L.hs_jax_load_checkpoints, hip_stream, buffers)
 
+    def train_interface(self):
+        """Manager::trainInterface (mgr.cpp:1338-1375) bound to this simulator: {role: {name: Tensor}} with the
+        reference's names and order — what `sim.jax()` hands to the learner."""
+        out = {}
+        for name, role, getter in train_interface():
+            out.setdefault(role, {})[name] = getattr(self, getter)() if getter else None
+        return out
+
     def jax(self, jax_gpu):
-        raise NotImplementedError(
+        """bindings.cpp:97-118 (JAXInterface::buildEntry).  The interface table and the four stream functions an
+        XLA custom call would invoke exist natively (hs_train_interface, hs_jax_init / step / save_checkpoints /
+        load_checkpoints = stream_init / stream_step / ...); registering them with XLA needs jaxlib, which is not
+        on the target.  The table is built first and travels on the exception."""
+        iface = self.train_interface()
+        err = NotImplementedError(
             "sim.jax(): the XLA custom-call registration needs jaxlib, which is not on the target (SURVEY §7 H8). "
-            "The stream functions it would register exist natively (hs_jax_init/step/save_checkpoints/"
-            "load_checkpoints, exposed as stream_init/stream_step/stream_save_checkpoints/stream_load_checkpoints); "
-            "Tensor.to_jax() hands the buffers over through DLPack.")
+            "The interface table (sim.train_interface(), attached to this exception as .train_interface) and the "
+            "stream functions it would register (stream_init / stream_step / stream_save_checkpoints / "
+            "stream_load_checkpoints) exist natively; Tensor.to_jax() hands the buffers over through DLPack.")
+        err.train_interface = iface
+        raise err
+
+    def device_status(self):
+        """hs_get_device_status: sticky device-side conditions (dropped broadphase pairs, expired waits, graphs)."""
+        st = _native.HsDeviceStatus()
+        _check(self._L.hs_get_device_status(self._h, C.byref(st)))
+        return {"dropped_dd_pairs": int(st.dropped_dd_pairs), "dropped_static_pairs": int(st.dropped_static_pairs),
+                "dropped_candidate_pairs": int(st.dropped_dd_pairs + st.dropped_static_pairs),
+                "sched_error": int(st.sched_error), "graphs_in_use": bool(st.graphs_in_use)}
+
+    def warning(self):
+        """The library's last message for this thread (a warning after a successful call, e.g. dropped pairs)."""
+        return self._L.hs_last_error().decode()
 
     # ---- parity-test hooks (include/hideseek.h hs_debug_dump_*) ----
     def debug_bodies(self):
@@ -370,10 +269,4 @@ class HideAndSeekSimulator:
         return {"physics": out[0], "reset": out[1], "observe": out[2]}
 
 
-class _MadronaNamespace:
-    """`gpu_hideseek.madrona` submodule (bindings.cpp:21): only what scripts/ touch."""
-    ExecMode = _ExecMode
-    Tensor = Tensor
-
-
-madrona = _MadronaNamespace()
+from .sharded import ShardedSimulator  # noqa: E402

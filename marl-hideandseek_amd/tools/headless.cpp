@@ -25,20 +25,25 @@ int main(int argc, char **argv) {
     const bool rand_actions = argc > 4 && std::strcmp(argv[4], "--rand-actions") == 0;
     cfg.sim_flags = HS_FLAG_DEFAULT;
     cfg.rand_seed = 5;
-    cfg.min_hiders = cfg.max_hiders = 3;                 // src/headless.cpp:62-73
-    cfg.min_seekers = cfg.max_seekers = 3;
-    cfg.num_pbt_policies = 0;
+    cfg.min_hiders = cfg.max_hiders = 3;                 // src/headless.cpp:57-69
+    cfg.min_seekers = cfg.max_seekers = 2;
+    cfg.num_pbt_policies = 1;
     hs_sim *sim = nullptr;
     if (hs_create(&cfg, &sim) != HS_OK) { std::fprintf(stderr, "hs_create: %s\n", hs_last_error()); return 2; }
     if (hs_init(sim) != HS_OK) { std::fprintf(stderr, "hs_init: %s\n", hs_last_error()); return 2; }
-    const int agents = cfg.num_worlds * hs_agents_per_world(sim);
-    std::mt19937 rng(0);
-    std::uniform_int_distribution<int> act(0, 10), bin(0, 1);
+    std::random_device rd;
+    std::mt19937 rng(rd());
+    std::uniform_int_distribution<int32_t> act(0, 4);
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < num_steps; ++i) {
-        if (rand_actions) {                              // src/headless.cpp:78-93: host-side per-agent pokes
-            for (int a = 0; a < agents; a += 97)
-                hs_set_action(sim, a, act(rng), act(rng), act(rng), bin(rng), bin(rng));
+        if (rand_actions) {
+            // src/headless.cpp:79-93: two Manager::setAction pokes per world with values 0-4 and g = l = 0; the agent
+            // index is the reference's own `j * k` (agent 0 for k = 0, agent j for k = 1), kept as it is
+            for (int j = 0; j < cfg.num_worlds; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const int32_t x = act(rng), y = act(rng), r = act(rng);
+                    if (hs_set_action(sim, j * k, x, y, r, 0, 0) != HS_OK) { std::fprintf(stderr, "hs_set_action: %s\n", hs_last_error()); return 2; }
+                }
         }
         if (hs_step(sim) != HS_OK) { std::fprintf(stderr, "hs_step: %s\n", hs_last_error()); return 2; }
     }

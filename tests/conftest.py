@@ -38,5 +38,6 @@ def _built_artifacts():
     hs_build.build_lib()
     try:
         hs_build.build_headless()
+        hs_build.build_smallcap()
     except Exception:
         pass

@@ -1,0 +1,136 @@
+"""Device-side failure is surfaced (include/hideseek.h hs_device_status): dropped broadphase candidate pairs are
+counted and reported, an expired device-side wait turns into an error code, and HS_GRAPH=1 can be seen to be in use."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "marl-hideandseek_amd")
+
+
+def _child(code, env=None, timeout=300):
+    out = subprocess.run([sys.executable, "-c", f"import sys\nsys.path.insert(0, {PKG!r})\n" + code],
+                         env={**os.environ, **(env or {})}, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+STEP_LOOP = """
+import torch, gpu_hideseek
+sim = gpu_hideseek.HideAndSeekSimulator(exec_mode=1, gpu_id=0, num_worlds=256, sim_flags=0, rand_seed=3, min_hiders=2,
+      max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+sim.init()
+for s in range(12):
+    sim.step()
+st = sim.device_status()
+print("STATUS", st["dropped_dd_pairs"], st["dropped_static_pairs"], st["sched_error"], int(st["graphs_in_use"]))
+print("WARNING", sim.warning())
+"""
+
+
+def test_dropped_candidate_pairs_are_counted_and_reported():
+    """A build whose per-world capacities are 1 body-body and 1 body-static pair (libhideseek_smallcap.so) must
+    overflow within a few steps of 256 ordinary worlds — and say so; the normal build must report zero."""
+    import build as hs_build
+    small = hs_build.build_smallcap()
+    out = _child(STEP_LOOP, {"HS_LIB_PATH": small})
+    st = [l for l in out.splitlines() if l.startswith("STATUS")][0].split()
+    assert int(st[1]) + int(st[2]) > 0, out
+    assert "dropped" in [l for l in out.splitlines() if l.startswith("WARNING")][0]
+    out = _child(STEP_LOOP)
+    st = [l for l in out.splitlines() if l.startswith("STATUS")][0].split()
+    assert st[1:4] == ["0", "0", "0"], out
+
+
+def test_sched_error_turns_into_an_error_code():
+    """hs_debug_inject_sched_error plants what an expired wait of the HS_OVERLAP=1 schedule writes; the blocking step
+    and the next asynchronous call must both fail instead of handing stale observations over as HS_OK."""
+    import torch
+    import gpu_hideseek
+    sim = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=64, sim_flags=0, rand_seed=1,
+        min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+    sim.init()
+    sim.step()
+    assert sim.device_status()["sched_error"] == 0
+    assert sim._L.hs_debug_inject_sched_error(sim._h, 1) == 0
+    with pytest.raises(RuntimeError, match="wait expired"):
+        sim.step()
+    strm = torch.cuda.Stream()
+    with pytest.raises(RuntimeError, match="wait expired"):
+        sim.step_async(strm.cuda_stream)
+    assert sim.device_status()["sched_error"] == 1
+    assert sim._L.hs_debug_inject_sched_error(sim._h, 0) == 0
+
+
+def test_graph_mode_is_visible():
+    out = _child(STEP_LOOP, {"HS_GRAPH": "1"})
+    assert [l for l in out.splitlines() if l.startswith("STATUS")][0].split()[4] == "1", out
+    out = _child(STEP_LOOP, {"HS_GRAPH": "0"})
+    assert [l for l in out.splitlines() if l.startswith("STATUS")][0].split()[4] == "0", out
+
+
+def test_sharded_front_end_equals_the_monolithic_run():
+    """ShardedSimulator with two handles on the one GPU of this box (each with its own stream, started together)
+    reproduces a single 600-world handle bit for bit: bodies, gathered observations, scattered actions."""
+    import torch
+    import gpu_hideseek
+    N, A = 600, 4
+    kw = dict(sim_flags=0, rand_seed=11, min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+    mono = gpu_hideseek.HideAndSeekSimulator(exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=N, **kw)
+    shd = gpu_hideseek.ShardedSimulator([0, 0, 0], N, **kw)
+    assert [s.num_worlds for s in shd.shards] == [200, 200, 200] and [s.world_offset for s in shd.shards] == [0, 200, 400]
+    mono.init(); shd.init()
+    act_m = mono.action_tensor().to_torch()
+    act_s = shd.action_tensor()
+    assert act_s.shape == (N * A, 5)
+    rng = np.random.default_rng(5)
+    for step in range(20):
+        a = torch.from_numpy(rng.integers(-5, 5, size=(N * A, 5)).astype(np.int32))
+        a[:, 2:] = 0
+        act_m.copy_(a)
+        act_s.scatter(a)
+        mono.step(); shd.step()
+    for name in ("self_data", "lidar", "box_data", "reward", "global_positions", "seed"):
+        m = getattr(mono, name + "_tensor")().to_torch().cpu()
+        g = getattr(shd, name + "_tensor")().gather()
+        assert g.is_pinned() and torch.equal(g.view(torch.int32), m.view(torch.int32)), name
+    mb = mono.debug_bodies()[0]
+    sb = np.concatenate([s.debug_bodies()[0] for s in shd.shards])
+    assert np.array_equal(mb.view(np.int32), sb.view(np.int32))
+    shd.trigger_reset(399, 1)
+    assert shd.shards[1].reset_tensor().to_torch()[199, 0].item() == 1
+    shd.set_action(401 * A + 2, 1, 2, 3, 0, 0)
+    assert shd.shards[2].action_tensor().to_torch()[1 * A + 2].tolist() == [1, 2, 3, 0, 0]
+    assert shd.device_status()["dropped_candidate_pairs"] == 0
+    shd.close()
+
+
+def test_overlap_schedule_through_the_stream_entry_point():
+    """HS_OVERLAP=1 on the asynchronous path (evFork / evJoin) gives the same state as the eager run."""
+    code = """
+import hashlib, torch, gpu_hideseek
+sim = gpu_hideseek.HideAndSeekSimulator(exec_mode=1, gpu_id=0, num_worlds=900, sim_flags=0, rand_seed=9, min_hiders=2,
+      max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+sim.init()
+strm = torch.cuda.Stream()
+act = sim.action_tensor().to_torch()
+for s in range(25):
+    g = torch.arange(act.shape[0], device=act.device)
+    act[:, 0] = ((g * 7 + s) % 10 - 5).int(); act[:, 1] = ((g * 3 + 2 * s) % 10 - 5).int()
+    strm.wait_stream(torch.cuda.current_stream())
+    sim.step_async(strm.cuda_stream)
+    strm.synchronize()
+b, m = sim.debug_bodies()
+h = hashlib.sha256(b.tobytes() + sim.lidar_tensor().to_torch().cpu().numpy().tobytes()
+                   + sim.reward_tensor().to_torch().cpu().numpy().tobytes()).hexdigest()
+print("DIGEST", h, sim.device_status()["sched_error"])
+"""
+    a = [l for l in _child(code, {"HS_OVERLAP": "1"}).splitlines() if l.startswith("DIGEST")][0]
+    b = [l for l in _child(code, {"HS_OVERLAP": "0"}).splitlines() if l.startswith("DIGEST")][0]
+    assert a == b and a.split()[2] == "0"
