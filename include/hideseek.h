@@ -205,18 +205,14 @@ int32_t hs_train_interface(const hs_iface_entry **entries);
  *   dropped_dd_pairs / dropped_static_pairs: broadphase candidate pairs beyond the per-world capacities (16 body-body,
  *     24 body-static per substep) that were discarded — the oracle discards the same ones, so parity cannot see it.
  *     Sticky totals since hs_create.  hs_step still returns HS_OK; hs_last_error() carries a warning.
- *   sched_error: non-zero when a bounded device-side wait expired (HS_OVERLAP=1 schedule); the step that saw it
- *     returns HS_ERR_HIP, and so does the next call of an asynchronous entry point.
  *   graphs_in_use: 1 when HS_GRAPH=1 took effect and steps are replayed as HIP graphs. */
 typedef struct hs_device_status {
     int64_t dropped_dd_pairs;
     int64_t dropped_static_pairs;
-    int32_t sched_error;
     int32_t graphs_in_use;
+    int32_t reserved;
 } hs_device_status;
 int32_t hs_get_device_status(hs_sim *sim, hs_device_status *out);
-/* Test hook: plants `code` in the device-side sched_error word as an expired wait would. */
-int32_t hs_debug_inject_sched_error(hs_sim *sim, int32_t code);
 
 /* maxAgentsPerWorld (src/mgr.cpp:684). */
 int32_t hs_agents_per_world(const hs_sim *sim);

@@ -1,5 +1,5 @@
 // libhideseek.so — host side of the C ABI declared in include/hideseek.h.
-// Owns the HBM allocations, launches the three kernels of a step on one HIP stream and
+// Owns the HBM allocations, launches the two kernels of a step on the handle's HIP stream and
 // hands out non-owning tensor descriptors (replaces Manager::Impl, src/mgr.cpp:86-437, 674-822).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,7 +14,6 @@
 #include "hs_k_observe.h"
 #include "hs_k_pipeline.h"
 #include "hs_solver.h"
-static_assert(hs::kObsGroupWorlds == hs::kPhysWorlds, "k_observe takes worlds by k_physics workgroup");
 
 namespace {
 
@@ -41,12 +40,6 @@ struct hs_sim {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[3] = {0.f, 0.f, 0.f};
     bool initialised = false;
-    bool overlap = false;                  // env HS_OVERLAP=1: dependency schedule between k_physics and k_observe (measured +2 %, opt-in)
-    bool overlapped_last = false;          // the last launch used obs_stream
-    int num_cus = 0;                       // compute units of the device
-    int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
-    hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower than two direct launches)
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};     // physics, observe
     hipStream_t stream = nullptr;          // this handle's own stream: hs_init / hs_step / checkpoints run here
@@ -75,12 +68,10 @@ void set_desc(hs_sim *s, int id, void *ptr, int dtype, std::initializer_list<int
     for (; i < 4; ++i) d.dims[i] = 1;
 }
 
-void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
-    hs::SimState S = s->S;
-    S.stepPar = step_par;
+void launch_observe(hs_sim *s, hipStream_t strm) {
+    const hs::SimState &S = s->S;
     if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
-    // with the dependency schedule the grid is whole physics groups (a short last group's extra workgroups exit)
-    const int N = step_par >= 0 ? (S.N + hs::kPhysWorlds - 1) / hs::kPhysWorlds * hs::kPhysWorlds : S.N;
+    const int N = S.N;
     const int nt = (s->A * hs::kRaysPerAgent + 63) / 64 * 64;      // one lane per ray, whole waves
     if (nt <= 64) hipLaunchKernelGGL(hs::k_observe<64>, dim3(N), dim3(64), 0, strm, S);
     else if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);
@@ -89,50 +80,21 @@ void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
     else hipLaunchKernelGGL(hs::k_observe<320>, dim3(N), dim3(320), 0, strm, S);
 }
 
-int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7, bool allow_overlap = false,
-                      bool host_joins = false) {
-    hs::SimState S = s->S;
+// One step = k_physics (movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results, reset: one
+// persistent kernel, a workgroup per kPhysWorlds worlds, hs_k_pipeline.h) then k_observe.  Manager::init = k_reset
+// then k_observe.  `stages`: 1 physics, 2 reset (init only), 4 observe.
+int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7) {
+    const hs::SimState &S = s->S;
     const int N = S.N;
-    const bool skip_obs = (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
-    // Dependency schedule: k_observe is launched on its own stream right away and its workgroups take world groups
-    // in the order k_physics finishes them, so the observations of early groups fill the CUs that the slow groups
-    // leave idle (worlds differ in how many contacts they hold; the slowest physics workgroup is ~12 % behind the mean).
-    // Only when every physics workgroup is resident from the start (one per CU): then none of them ever waits for a
-    // CU that spinning k_observe workgroups hold.
-    const bool overlap = allow_overlap && s->overlap && !first && stages == 7 && !skip_obs &&
-                         (N + hs::kPhysWorlds - 1) / hs::kPhysWorlds <= s->num_cus;
-    S.stepPar = overlap ? s->sched_par : -1;
-    s->overlapped_last = false;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
-    // (a blocking hs_step has synchronised everything before and joins the two streams on the host: cross-stream
-    // event waits cost tens of microseconds each)
-    if (overlap && !host_joins) {
-        HS_HIP(hipEventRecord(s->evFork, strm));
-        HS_HIP(hipStreamWaitEvent(s->obs_stream, s->evFork, 0));
-    }
-    if (!first && (stages & 1)) {
-        // movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results, reset: one persistent kernel,
-        // a workgroup per kPhysWorlds worlds (hs_k_pipeline.h)
+    if (!first && (stages & 1))
         hipLaunchKernelGGL(hs::k_physics, dim3((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds), dim3(hs::kPhysThreads), 0, strm, S);
-    }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
     if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
-    if (overlap) {
-        hipLaunchKernelGGL(hs::k_gate, dim3(1), dim3(64), 0, s->obs_stream, S, (N + hs::kPhysWorlds - 1) / hs::kPhysWorlds);
-        launch_observe(s, s->obs_stream, s->sched_par);
-        if (prof) HS_HIP(hipEventRecord(s->ev[3], s->obs_stream));
-        if (!host_joins) {
-            HS_HIP(hipEventRecord(s->evJoin, s->obs_stream));
-            HS_HIP(hipStreamWaitEvent(strm, s->evJoin, 0));
-        }
-        s->overlapped_last = true;
-        s->sched_par ^= 1;
-    } else {
-        if (stages & 4) launch_observe(s, strm);
-        if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
-    }
+    if (stages & 4) launch_observe(s, strm);
+    if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -142,8 +104,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
 // events between the graph launches.  It paid off while physics was ~40 launches per step; with the persistent
 // physics kernel a step is two launches and the direct launches are faster.  When capture or instantiation fails
 // the handle falls back to direct launches and hs_get_device_status reports graphs_in_use = 0.
-int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false) {
-    if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling, 7, true, host_joins);
+int launch_step(hs_sim *s, hipStream_t strm, bool first) {
+    if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling);
     const bool skip_obs = (s->S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
     const int ngraphs = skip_obs ? 1 : 2;
     if (!s->graph_exec[0]) {
@@ -179,9 +141,6 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false
 int poll_status(hs_sim *s) {
     if (!s->host_flag || !*(volatile int *)s->host_flag) return HS_OK;
     HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
-    if (s->status_cache[2] != 0)
-        return fail(HS_ERR_HIP, "device-side wait expired (sched_error " + std::to_string(s->status_cache[2]) +
-                                "): the observations of this step are incomplete");
     g_err = "warning: broadphase candidate pairs beyond the per-world capacity were dropped (" +
             std::to_string(s->status_cache[0]) + " body-body, " + std::to_string(s->status_cache[1]) + " body-static so far)";
     return HS_OK;
@@ -240,15 +199,10 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
-    HS_ALLOC(S.bppos, 3 * D * N); HS_ALLOC(S.bprot, 4 * D * N); HS_ALLOC(S.blo, 3 * D * N); HS_ALLOC(S.bhi, 3 * D * N);
     HS_ALLOC(S.gman, 2 * D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
     HS_ALLOC(S.ndd, N); HS_ALLOC(S.nsc, N); HS_ALLOC(S.ddPair, hs::kMaxDDCand * N); HS_ALLOC(S.scPair, hs::kMaxSCand * N);
     HS_ALLOC(S.wflags, N);
     HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.bodyList, N * D); HS_ALLOC(S.ddwList, 2 * N);
-    { const size_t G = (N + hs::kPhysWorlds - 1) / hs::kPhysWorlds;
-      if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
-      HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
-    S.stepPar = -1;
     HS_ALLOC(S.phaseTicks, 10 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
     HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
@@ -268,13 +222,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
         if (hipEventCreate(&e) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipEventCreate failed"); }
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
-    if (const char *e = getenv("HS_OVERLAP")) s->overlap = atoi(e) != 0;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->gpu_id) == hipSuccess) s->num_cus = prop.multiProcessorCount; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->obs_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
+        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
     S.wbeg = 0; S.wcnt = (int)N;
     std::memset(s->exports, 0, sizeof(s->exports));
     const int64_t n = (int64_t)N, r = (int64_t)R;
@@ -309,9 +258,6 @@ void hs_destroy(hs_sim *s) {
     hipDeviceSynchronize();
     for (void *p : s->allocs) hipFree(p);
     for (auto &e : s->ev) if (e) hipEventDestroy(e);
-    if (s->evFork) hipEventDestroy(s->evFork);
-    if (s->evJoin) hipEventDestroy(s->evJoin);
-    if (s->obs_stream) hipStreamDestroy(s->obs_stream);
     if (s->evIn) hipEventDestroy(s->evIn);
     if (s->stream) hipStreamDestroy(s->stream);
     if (s->host_flag) hipHostFree(s->host_flag);
@@ -347,7 +293,7 @@ int32_t hs_step_begin(hs_sim *s) {
     if (s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_step_begin: the previous step was not ended");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     int rc = order_after_default_stream(s);
-    if (rc == HS_OK) rc = launch_step(s, s->stream, false, true);
+    if (rc == HS_OK) rc = launch_step(s, s->stream, false);
     if (rc != HS_OK) return rc;
     s->step_open = true;
     return HS_OK;
@@ -359,13 +305,8 @@ int32_t hs_step_end(hs_sim *s) {
     s->step_open = false;
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     HS_HIP(hipStreamSynchronize(s->stream));
-    if (s->overlapped_last) HS_HIP(hipStreamSynchronize(s->obs_stream));
-    if (s->profiling) {
+    if (s->profiling)
         for (int i = 0; i < 3; ++i) HS_HIP(hipEventElapsedTime(&s->last_ms[i], s->ev[i], s->ev[i + 1]));
-        // under the dependency schedule ev[3] is recorded on the observation stream: ev[2]..ev[3] is then the span
-        // from the end of k_physics' launch slot to the end of k_observe, not a kernel duration
-        if (s->overlapped_last) s->last_ms[2] = -1.f;
-    }
     return poll_status(s);
 }
 
@@ -377,8 +318,7 @@ int32_t hs_step(hs_sim *s) {
 int32_t hs_step_async(hs_sim *s, void *hip_stream) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int rc = poll_status(s);               // a failure of an earlier asynchronous step surfaces here
-    return rc != HS_OK ? rc : launch_step(s, (hipStream_t)hip_stream, false);
+    return launch_step(s, (hipStream_t)hip_stream, false);
 }
 
 int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
@@ -513,8 +453,7 @@ int32_t hs_jax_step(hs_sim *s, void *hip_stream, void **buffers) {
     hipStream_t strm = (hipStream_t)hip_stream;
     const hs::SimState &S = s->S;
     const size_t N = (size_t)S.N, R = N * s->A;
-    int rc = poll_status(s);               // a failure of an earlier asynchronous step surfaces here
-    if (rc == HS_OK) rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
+    int rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
     if (rc == HS_OK) rc = copy_dd(S.xReset, *buffers++, N * 4, strm);
     if (rc == HS_OK) rc = copy_dd(S.xPolicy, *buffers++, R * 4, strm);
     if (rc == HS_OK) rc = launch_step(s, strm, false);
@@ -661,16 +600,7 @@ int32_t hs_get_device_status(hs_sim *s, hs_device_status *out) {
     HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
     out->dropped_dd_pairs = s->status_cache[0];
     out->dropped_static_pairs = s->status_cache[1];
-    out->sched_error = s->status_cache[2];
     out->graphs_in_use = (s->use_graph && s->graph_exec[0]) ? 1 : 0;
-    return HS_OK;
-}
-
-int32_t hs_debug_inject_sched_error(hs_sim *s, int32_t code) {
-    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
-    HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    HS_HIP(hipMemcpy(s->S.status + 2, &code, sizeof(code), hipMemcpyHostToDevice));
-    *s->host_flag = code != 0 ? 1 : *s->host_flag;
     return HS_OK;
 }
 

@@ -73,35 +73,11 @@ constexpr unsigned kKeyMiss = 0xffffffffu;
 
 // NT = threads per world = A*46 rays rounded up to whole waves (192 for the 4-agent benchmark): every
 // lane of pass 1 / pass 3 has a ray.
-constexpr int kObsGroupWorlds = 64;     // = kPhysWorlds (hs_k_pipeline.h): worlds per workgroup of k_physics
 template <int NT>
 __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     __shared__ ObsShared sh;
-    __shared__ int sh_group;
     const int tid = threadIdx.x;
-    int w = blockIdx.x;
-    if (S.stepPar >= 0) {
-        // Dependency schedule: this workgroup takes world (blockIdx % 64) of the (blockIdx / 64)-th physics group to
-        // FINISH, and waits for it (agent-scope acquire by one lane, then the barrier; bounded spin so that a bug
-        // cannot hang the GPU).  The physics workgroups are all resident and never wait, so this always ends.
-        if (tid == 0) {
-            const int ngroups = (S.N + kObsGroupWorlds - 1) / kObsGroupWorlds;
-            const int *slot = &S.doneList[S.stepPar * ngroups + blockIdx.x / kObsGroupWorlds];
-            int g = -1;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                g = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (g >= 0) break;
-                __builtin_amdgcn_s_sleep(32);
-            }
-            if (g < 0) { S.status[2] = 1; *S.hostFlag = 1; }
-            sh_group = g;
-        }
-        __syncthreads();
-        const int g = sh_group;
-        if (g < 0) return;
-        w = g * kObsGroupWorlds + (blockIdx.x % kObsGroupWorlds);
-        if (w >= S.N) return;
-    }
+    const int w = blockIdx.x;
     const int A = S.A;
     stage_world<NT>(S, w, sh, tid);
     if (tid < 30) {       // lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent

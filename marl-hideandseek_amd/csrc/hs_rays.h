@@ -21,6 +21,15 @@ struct WorldGeom {
     int numWalls, numPlanes;
     float wall[kMaxWalls][4];     // cx, cy, hx, hy
     float plane[kMaxPlanes][4];   // nx, ny, nz, d
+    // the geometry-view interface of trace_ray (the physics kernel has a second implementation over its
+    // LDS-resident columns, hs_k_pipeline.h ResGeom)
+    HSD int g_meta(int i) const { return meta[i]; }
+    HSD V3 g_pos(int i) const { return {pos[i][0], pos[i][1], pos[i][2]}; }
+    HSD Q g_rot(int i) const { return {rot[i][0], rot[i][1], rot[i][2], rot[i][3]}; }
+    HSD int g_num_walls() const { return numWalls; }
+    HSD float g_wall(int k, int c) const { return wall[k][c]; }
+    HSD int g_num_planes() const { return numPlanes; }
+    HSD float g_plane(int p, int c) const { return plane[p][c]; }
 };
 
 HSD V3 geom_pos(const WorldGeom &g, int i) { return {g.pos[i][0], g.pos[i][1], g.pos[i][2]}; }
@@ -112,35 +121,36 @@ HSD float obj_bound_r2(int obj) {
     return obj == OBJ_BOX ? 17.5625f * 1.02f : (obj == OBJ_RAMP ? 6.f * 1.02f : 3.f * 1.02f);
 }
 
-HSD int trace_ray(const WorldGeom &g, V3 o, V3 d, float tmax, float *t_out) {
+template <class G>
+HSD int trace_ray(const G &g, V3 o, V3 d, float tmax, float *t_out) {
     int hit = -1; float best = tmax;
     const float dd2 = dot(d, d);
     for (int i = 0; i < kNumDSlots; ++i) {
-        int m = g.meta[i];
+        int m = g.g_meta(i);
         if (m == 0) continue;
         int obj = meta_obj(m);
         // conservative cull: the ray misses the hull's bounding sphere, or the sphere lies behind the origin
-        const V3 mo = o - geom_pos(g, i);
+        const V3 mo = o - g.g_pos(i);
         const float b = dot(mo, d), cc = dot(mo, mo) - obj_bound_r2(obj);
         if (cc > 0.f && (b > 0.f || b * b < dd2 * cc * 0.999f)) continue;
-        Q qi = qinv(geom_rot(g, i));
+        Q qi = qinv(g.g_rot(i));
         V3 ol = qrot(qi, mo), dl = qrot(qi, d);
         float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
         if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = i; }
     }
     const V3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
-    const int nw = g.numWalls;
+    const int nw = g.g_num_walls();
     for (int k = 0; k < nw; ++k) {
-        V3 ol = {o.x - g.wall[k][0], o.y - g.wall[k][1], o.z - 1.25f};
-        float t = ray_wall(ol, d, inv, {g.wall[k][2], g.wall[k][3], 1.25f});
+        V3 ol = {o.x - g.g_wall(k, 0), o.y - g.g_wall(k, 1), o.z - 1.25f};
+        float t = ray_wall(ol, d, inv, {g.g_wall(k, 2), g.g_wall(k, 3), 1.25f});
         if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + k; }
     }
-    const int np = g.numPlanes;
+    const int np = g.g_num_planes();
     for (int p = 0; p < np; ++p) {
-        V3 n = {g.plane[p][0], g.plane[p][1], g.plane[p][2]};
+        V3 n = {g.g_plane(p, 0), g.g_plane(p, 1), g.g_plane(p, 2)};
         float dn = dot(n, d);
         if (!(dn < 0.f)) continue;
-        float dist = dot(n, o) - g.plane[p][3];
+        float dist = dot(n, o) - g.g_plane(p, 3);
         if (dist < 0.f) continue;
         float t = -dist / dn;
         if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitPlaneBase + p; }

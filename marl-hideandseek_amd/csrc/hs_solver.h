@@ -1,4 +1,4 @@
-// XPBD contact / joint solver pieces and the actionSystem, shared by the phases of the physics kernel
+// XPBD contact / joint solver pieces shared by the phases of the physics kernel
 // (hs_k_pipeline.h).  Replaces madrona::phys' solver (spliced in at src/sim.cpp:1162-1163; engine
 // source absent — DESIGN.md "Engine decisions"): per contact point a normal correction with static
 // friction in the position pass, dynamic friction and restitution 0 in the velocity pass.
@@ -14,15 +14,6 @@ namespace hs {
 struct alignas(16) ManDD { int a, b, np; float muS, muD; float n[3]; float rA[4][3]; float rB[4][3]; float lam[4]; };
 struct alignas(16) ManS { int np; float muS, muD; float n[3]; float pad[2]; float rA[4][3]; float offB[4]; float lam[4]; };
 static_assert(sizeof(ManDD) == 144 && sizeof(ManS) == 112, "manifold layout");
-
-// One world's geometry + action state staged in LDS for the (rare) lock / grab ray casts.
-struct ActWorld {
-    WorldGeom g;
-    int grabOther[kMaxAgents];
-    float grabData[kMaxAgents][kGrabWords];
-    int actGL[kMaxAgents];
-    int teams;
-};
 
 HSD bool has_mass_i(float invM, V3 invI) { return invM != 0.f || invI.z != 0.f || invI.x != 0.f || invI.y != 0.f; }
 
@@ -171,57 +162,6 @@ HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float la
     if (HAS_B) {
         B.lin = B.lin - p * B.invM;
         B.ang = B.ang - apply_inv_inertia(B, cross(rBw, p));
-    }
-}
-
-// actionSystem for one world, agents in interface order (executed by lane 0 of the group).
-HSD void action_system(ActWorld &pw, int A_) {
-    for (int i = 0; i < A_; ++i) {
-        const int fl = pw.actGL[i];
-        if (fl == 0) continue;
-        const int type = team_agent_type(pw.teams, i);
-        const int slot = kAgentSlot0 + i;
-        const V3 mpos = geom_pos(pw.g, slot);
-        const Q mrot = geom_rot(pw.g, slot);
-        if (fl & 2) {   // lock
-            float t; V3 o = mpos + V3{0.f, 0.f, 0.5f};
-            int hit = trace_ray(pw.g, o, qrot(mrot, {0.f, 1.f, 0.f}), 2.5f, &t);
-            if (hit >= 0 && hit < kNumDSlots) {
-                const int m = pw.g.meta[hit];
-                const int obj = meta_obj(m), resp = meta_resp(m), owner = meta_owner(m);
-                if (resp == RESP_STATIC) {
-                    if ((type == AGENT_SEEKER && owner == OWNER_SEEKER) || (type == AGENT_HIDER && owner == OWNER_HIDER))
-                        pw.g.meta[hit] = meta_pack(obj, RESP_DYNAMIC, OWNER_NONE);
-                } else if (owner == OWNER_NONE) {
-                    pw.g.meta[hit] = meta_pack(obj, RESP_STATIC, type == AGENT_HIDER ? OWNER_HIDER : OWNER_SEEKER);
-                }
-            }
-        }
-        if (fl & 1) {   // grab
-            if (pw.grabOther[i] >= 0) {
-                pw.grabOther[i] = -1;
-            } else {
-                float t; V3 o = mpos + V3{0.f, 0.f, 0.5f};
-                V3 dir = qrot(mrot, {0.f, 1.f, 0.f});
-                int hit = trace_ray(pw.g, o, dir, 2.5f, &t);
-                if (hit >= 0 && hit < kNumDSlots) {
-                    const int m = pw.g.meta[hit];
-                    if (meta_owner(m) == OWNER_NONE && meta_resp(m) == RESP_DYNAMIC) {
-                        V3 hit_pos = o + dir * t;
-                        Q erot = geom_rot(pw.g, hit);
-                        V3 r2 = qrot(qinv(erot), hit_pos - geom_pos(pw.g, hit));
-                        Q at2 = qnormalize(qmul(qinv(erot), mrot));
-                        pw.grabOther[i] = hit;
-                        float *gd = pw.grabData[i];
-                        gd[0] = r2.x; gd[1] = r2.y; gd[2] = r2.z;
-                        gd[3] = at2.w; gd[4] = at2.x; gd[5] = at2.y; gd[6] = at2.z;
-                        gd[7] = t - 1.25f;
-                        gd[8] = 0.f; gd[9] = 1.25f; gd[10] = 0.5f;            // r1 = 1.25 fwd + 0.5 up (sim.cpp:343-344)
-                        gd[11] = 1.f; gd[12] = 0.f; gd[13] = 0.f; gd[14] = 0.f;  // attachRot1 = identity
-                    }
-                }
-            }
-        }
     }
 }
 

@@ -53,29 +53,20 @@ struct SimState {
     float *xLidar, *xReward, *xGlobalPos, *xEpisodeResult;
     int32_t *xCkptCtrl;    // [N]  CheckpointControl::trigger (sim.hpp:279-281)
     uint8_t *xCkpt;        // [N][sizeof(hs_checkpoint)]  (include/hideseek.h, sim.hpp:283-313)
-    // --- substep scratch of the physics pipeline (hs_k_pipeline.h), all SoA across worlds
-    float *bppos, *bprot;  // [3][17][N], [4][17][N]  pose at the start of the substep
-    float *blo, *bhi;      // [3][17][N]  hull AABBs
+    // --- substep scratch of the physics kernel (hs_k_pipeline.h) that does not fit its LDS-resident working set,
+    // all SoA across worlds
     int *gman;             // [2][17][N] (double-buffered by substep parity)     ground manifold: np | vertex ids << 4 | has-static-candidates << 30
     float *goff, *glam;    // [4][17][N]  ground manifold plane offsets / accumulated multipliers
     int *ndd, *nsc;        // [N]         candidate counts
     int *ddPair, *scPair;  // [kMaxDDCand][N] a | b << 8 ; [kMaxSCand][N] body | static << 8
     int *wflags;           // [N]         1 = world has a grab joint
     void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
-    int *bodyList;         // [N][17] existing bodies of a workgroup's worlds, compacted once per step (w << 5 | slot)
+    int *bodyList;         // [N][17] existing bodies of a workgroup's worlds, compacted once per step (local world << 5 | slot)
     int *satList, *wallList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
-    // --- dependency schedule between k_physics and k_observe (hideseek.hip launch_step): workgroup ids of k_physics
-    // in the order they finished, double-buffered by step parity
-    int *doneList;         // [2][groups]  -1 = not finished yet
-    int *doneTickets;      // [2]
-    int *startedCount;     // [2] physics workgroups that have started (k_gate holds k_observe back until all have)
-    int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, sched error, -
+    int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, -, -
                            // (include/hideseek.h hs_device_status); bumped only when something happens
     int *hostFlag;         // pinned host word (device-visible): set to 1 together with any change of status
-    int stepPar;           // parity of this step, or -1: k_observe does not wait (init, checkpoints, graph replay)
     long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
-    int *counters;         // [2][4] list lengths (sat box items, wall bodies, ddw, sat ramp items), double-buffered by substep
-                           // parity; set by k_physics to its workgroup's LDS copy
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }

@@ -234,12 +234,12 @@ class HideAndSeekSimulator:
         raise err
 
     def device_status(self):
-        """hs_get_device_status: sticky device-side conditions (dropped broadphase pairs, expired waits, graphs)."""
+        """hs_get_device_status: sticky device-side conditions (dropped broadphase pairs) and whether graphs are in use."""
         st = _native.HsDeviceStatus()
         _check(self._L.hs_get_device_status(self._h, C.byref(st)))
         return {"dropped_dd_pairs": int(st.dropped_dd_pairs), "dropped_static_pairs": int(st.dropped_static_pairs),
                 "dropped_candidate_pairs": int(st.dropped_dd_pairs + st.dropped_static_pairs),
-                "sched_error": int(st.sched_error), "graphs_in_use": bool(st.graphs_in_use)}
+                "graphs_in_use": bool(st.graphs_in_use)}
 
     def warning(self):
         """The library's last message for this thread (a warning after a successful call, e.g. dropped pairs)."""

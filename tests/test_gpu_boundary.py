@@ -145,9 +145,6 @@ def test_graph_replay_and_eager_launch_agree():
     kernel's worlds-per-workgroup."""
     ref = _run_variant({"HS_GRAPH": "1"})
     assert _run_variant({"HS_GRAPH": "0"}) == ref
-    # opt-in dependency schedule: k_observe beside k_physics, taking world groups in the order physics finishes them
-    assert _run_variant({"HS_GRAPH": "0", "HS_OVERLAP": "1"}) == ref
-    assert _run_variant({"HS_GRAPH": "0", "HS_OVERLAP": "1"}, n=16000, steps=6) == _run_variant({"HS_GRAPH": "0"}, n=16000, steps=6)
     assert _run_variant({"HS_GRAPH": "0"}, n=301)[:6] == "DIGEST"
 
 
