@@ -12,7 +12,7 @@
 #include "hs_state.h"
 #include "hs_k_reset.h"
 #include "hs_k_observe.h"
-#include "hs_k_pipeline.h"
+#include "hs_k_physics.h"
 #include "hs_solver.h"
 
 namespace {
@@ -81,14 +81,14 @@ void launch_observe(hs_sim *s, hipStream_t strm) {
 }
 
 // One step = k_physics (movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results, reset: one
-// persistent kernel, a workgroup per kPhysWorlds worlds, hs_k_pipeline.h) then k_observe.  Manager::init = k_reset
+// kernel, a wave per octet of 8 worlds, hs_k_physics.h) then k_observe.  Manager::init = k_reset
 // then k_observe.  `stages`: 1 physics, 2 reset (init only), 4 observe.
 int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7) {
     const hs::SimState &S = s->S;
     const int N = S.N;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first && (stages & 1))
-        hipLaunchKernelGGL(hs::k_physics, dim3((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds), dim3(hs::kPhysThreads), 0, strm, S);
+        hipLaunchKernelGGL(hs::k_physics, dim3((N + hs::kTile - 1) / hs::kTile), dim3(hs::kPhysThreads), 0, strm, S);
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
     if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
@@ -148,6 +148,20 @@ int poll_status(hs_sim *s) {
 
 }  // namespace
 
+namespace {
+// Host copy of a tiled column (hs_state.h Col): element (row, world) at ((w / 8) * ROWS + row) * 8 + w % 8.
+template <typename T, int ROWS>
+struct HostCol {
+    std::vector<T> v;
+    int load(const hs::Col<T, ROWS> &c, size_t n) {
+        v.resize((n + hs::kTile - 1) / hs::kTile * hs::kTile * ROWS);
+        HS_HIP(hipMemcpy(v.data(), c.p, v.size() * sizeof(T), hipMemcpyDeviceToHost));
+        return HS_OK;
+    }
+    T operator()(size_t row, size_t w) const { return v[((w >> 3) * ROWS + row) * hs::kTile + (w & 7)]; }
+};
+}  // namespace
+
 extern "C" {
 
 const char *hs_last_error(void) { return g_err.c_str(); }
@@ -184,13 +198,16 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     const int D = hs::kNumDSlots, AG = hs::kMaxAgents;
     int rc = HS_OK;
 #define HS_ALLOC(ptr, n) if ((rc = s->dalloc(&(ptr), (n))) != HS_OK) { hs_destroy(s); return rc; }
-    HS_ALLOC(S.bpos, 3 * D * N); HS_ALLOC(S.brot, 4 * D * N); HS_ALLOC(S.blin, 3 * D * N);
-    HS_ALLOC(S.bang, 3 * D * N); HS_ALLOC(S.bmeta, D * N); HS_ALLOC(S.aforce, 4 * AG * N);
-    HS_ALLOC(S.walls, 4 * hs::kMaxWalls * N); HS_ALLOC(S.planes, 4 * hs::kMaxPlanes * N);
+    // tiled columns (hs_state.h Col): whole octets, the padding worlds stay zero = empty slots
+    const size_t NP = (N + hs::kTile - 1) / hs::kTile * hs::kTile;
+#define HS_ALLOC_COL(col) HS_ALLOC((col).p, (size_t)(col).kRows * NP)
+    HS_ALLOC_COL(S.bpos); HS_ALLOC_COL(S.brot); HS_ALLOC_COL(S.blin); HS_ALLOC_COL(S.bang); HS_ALLOC_COL(S.bmeta);
+    HS_ALLOC_COL(S.aforce); HS_ALLOC_COL(S.walls); HS_ALLOC_COL(S.planes);
+    HS_ALLOC_COL(S.runningScores); HS_ALLOC_COL(S.grabOther); HS_ALLOC_COL(S.grabData);
+#undef HS_ALLOC_COL
     HS_ALLOC(S.numWalls, N); HS_ALLOC(S.numPlanes, N);
     HS_ALLOC(S.curWorldEpisode, N); HS_ALLOC(S.rngKeyA, N); HS_ALLOC(S.rngKeyB, N); HS_ALLOC(S.rngCount, N);
     HS_ALLOC(S.curEpisodeStep, N); HS_ALLOC(S.hiderTeamReward, N); HS_ALLOC(S.counts, N); HS_ALLOC(S.teams, N);
-    HS_ALLOC(S.runningScores, 2 * N); HS_ALLOC(S.grabOther, AG * N); HS_ALLOC(S.grabData, hs::kGrabWords * AG * N);
     HS_ALLOC(S.epKeyA, N); HS_ALLOC(S.epKeyB, N); HS_ALLOC(S.xCkptCtrl, N); HS_ALLOC(S.xCkpt, N * sizeof(hs_checkpoint));
     HS_ALLOC(S.xReset, N); HS_ALLOC(S.xPrep, R); HS_ALLOC(S.xAction, R * 5); HS_ALLOC(S.xSelfType, R);
     HS_ALLOC(S.xSeed, R * 2); HS_ALLOC(S.xDone, R); HS_ALLOC(S.xPolicy, R);
@@ -199,11 +216,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
-    HS_ALLOC(S.gman, 2 * D * N); HS_ALLOC(S.goff, 4 * D * N); HS_ALLOC(S.glam, 4 * D * N);
-    HS_ALLOC(S.ndd, N); HS_ALLOC(S.nsc, N); HS_ALLOC(S.ddPair, hs::kMaxDDCand * N); HS_ALLOC(S.scPair, hs::kMaxSCand * N);
-    HS_ALLOC(S.wflags, N);
-    HS_ALLOC(S.satList, N * (hs::kMaxDDCand + hs::kMaxSCand)); HS_ALLOC(S.wallList, N * D); HS_ALLOC(S.bodyList, N * D); HS_ALLOC(S.ddwList, 2 * N);
-    HS_ALLOC(S.phaseTicks, 10 * ((N + hs::kPhysWorlds - 1) / hs::kPhysWorlds));
+    HS_ALLOC(S.phaseTicks, 10 * (NP / hs::kTile));
     HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
     if (hipHostMalloc((void **)&s->host_flag, 64, hipHostMallocMapped) != hipSuccess) { s->host_flag = nullptr; hs_destroy(s); return fail(HS_ERR_HIP, "hipHostMalloc failed"); }
@@ -211,9 +224,9 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     if (hipHostGetDevicePointer((void **)&S.hostFlag, s->host_flag, 0) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipHostGetDevicePointer failed"); }
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
-        std::vector<int32_t> ones(N, 1), neg(AG * N, -1);
+        std::vector<int32_t> ones(N, 1), neg(AG * NP, -1);
         if (hipMemcpy(S.xReset, ones.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(S.grabOther, neg.data(), AG * N * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(S.grabOther.p, neg.data(), AG * NP * 4, hipMemcpyHostToDevice) != hipSuccess) {
             hs_destroy(s);
             return fail(HS_ERR_HIP, "initial upload failed");
         }
@@ -489,7 +502,7 @@ int32_t hs_jax_load_checkpoints(hs_sim *s, void *hip_stream, void **buffers) {
 int32_t hs_debug_phase_ticks(hs_sim *s, int64_t *out, int32_t max_groups) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int nb = (s->S.N + hs::kPhysWorlds - 1) / hs::kPhysWorlds;
+    int nb = (s->S.N + hs::kTile - 1) / hs::kTile;          // one workgroup (wave) per octet
     if (nb > max_groups) nb = max_groups;
     HS_HIP(hipMemcpy(out, s->S.phaseTicks, (size_t)nb * 10 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return nb;
@@ -498,22 +511,18 @@ int32_t hs_debug_phase_ticks(hs_sim *s, int64_t *out, int32_t max_groups) {
 int32_t hs_debug_dump_bodies(hs_sim *s, float *bodies, int32_t *meta) {
     if (!s || !bodies || !meta) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipDeviceSynchronize());
     const size_t N = s->S.N, D = hs::kNumDSlots;
-    std::vector<float> pos(3 * D * N), rot(4 * D * N), lin(3 * D * N), ang(3 * D * N);
-    std::vector<int32_t> m(D * N);
-    HS_HIP(hipMemcpy(pos.data(), s->S.bpos, pos.size() * 4, hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(rot.data(), s->S.brot, rot.size() * 4, hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(lin.data(), s->S.blin, lin.size() * 4, hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(ang.data(), s->S.bang, ang.size() * 4, hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(m.data(), s->S.bmeta, m.size() * 4, hipMemcpyDeviceToHost));
+    HostCol<float, 3 * hs::kNumDSlots> pos, lin, ang; HostCol<float, 4 * hs::kNumDSlots> rot; HostCol<int, hs::kNumDSlots> m;
+    int rc;
+    if ((rc = pos.load(s->S.bpos, N)) != HS_OK || (rc = rot.load(s->S.brot, N)) != HS_OK || (rc = lin.load(s->S.blin, N)) != HS_OK ||
+        (rc = ang.load(s->S.bang, N)) != HS_OK || (rc = m.load(s->S.bmeta, N)) != HS_OK) return rc;
     for (size_t w = 0; w < N; ++w)
         for (size_t i = 0; i < D; ++i) {
             float *o = bodies + (w * D + i) * 13;
-            for (size_t c = 0; c < 3; ++c) {
-                o[c] = pos[(c * D + i) * N + w]; o[7 + c] = lin[(c * D + i) * N + w]; o[10 + c] = ang[(c * D + i) * N + w];
-            }
-            for (size_t c = 0; c < 4; ++c) o[3 + c] = rot[(c * D + i) * N + w];
-            int32_t mm = m[i * N + w];
+            for (size_t c = 0; c < 3; ++c) { o[c] = pos(c * D + i, w); o[7 + c] = lin(c * D + i, w); o[10 + c] = ang(c * D + i, w); }
+            for (size_t c = 0; c < 4; ++c) o[3 + c] = rot(c * D + i, w);
+            int32_t mm = m(i, w);
             int32_t *om = meta + (w * D + i) * 3;
             if (mm == 0) { om[0] = -1; om[1] = 2; om[2] = 0; }
             else { om[0] = (mm & 0xff) - 1; om[1] = (mm >> 8) & 0xff; om[2] = (mm >> 16) & 0xff; }
@@ -524,10 +533,12 @@ int32_t hs_debug_dump_bodies(hs_sim *s, float *bodies, int32_t *meta) {
 int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
     if (!s || !walls || !info) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipDeviceSynchronize());
     const size_t N = s->S.N, K = hs::kMaxWalls;
-    std::vector<float> wl(4 * K * N);
+    HostCol<float, 4 * hs::kMaxWalls> wl;
+    int rc;
+    if ((rc = wl.load(s->S.walls, N)) != HS_OK) return rc;
     std::vector<int32_t> nw(N), np(N), cnt(N), step(N);
-    HS_HIP(hipMemcpy(wl.data(), s->S.walls, wl.size() * 4, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(nw.data(), s->S.numWalls, N * 4, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(np.data(), s->S.numPlanes, N * 4, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(cnt.data(), s->S.counts, N * 4, hipMemcpyDeviceToHost));
@@ -535,7 +546,7 @@ int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
     for (size_t w = 0; w < N; ++w) {
         for (size_t k = 0; k < K; ++k)
             for (size_t c = 0; c < 4; ++c)
-                walls[(w * K + k) * 4 + c] = (int)k < nw[w] ? wl[(c * K + k) * N + w] : 0.f;
+                walls[(w * K + k) * 4 + c] = (int)k < nw[w] ? wl(c * K + k, w) : 0.f;
         int32_t *m = info + w * 8;
         const int c = cnt[w];
         m[0] = nw[w]; m[1] = np[w]; m[2] = (c >> 12) & 15; m[3] = (c >> 16) & 15; m[4] = c & 15; m[5] = (c >> 4) & 15;

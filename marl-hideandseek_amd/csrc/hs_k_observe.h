@@ -44,28 +44,28 @@ HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
 template <int NT>
 HSD void stage_world(const SimState &S, int w, ObsShared &sh, int tid) {
     const int N = S.N;
-    for (int i = tid; i < kNumDSlots; i += NT) sh.g.meta[i] = S.bmeta[i * N + w];
+    for (int i = tid; i < kNumDSlots; i += NT) sh.g.meta[i] = S.bmeta(i, w);
     for (int i = tid; i < kNumDSlots * 3; i += NT) {
         int c = i / kNumDSlots, s = i % kNumDSlots;
-        sh.g.pos[s][c] = S.bpos[(c * kNumDSlots + s) * N + w];
-        sh.lin[s][c] = S.blin[(c * kNumDSlots + s) * N + w];
-        sh.ang[s][c] = S.bang[(c * kNumDSlots + s) * N + w];
+        sh.g.pos[s][c] = S.bpos(c * kNumDSlots + s, w);
+        sh.lin[s][c] = S.blin(c * kNumDSlots + s, w);
+        sh.ang[s][c] = S.bang(c * kNumDSlots + s, w);
     }
     for (int i = tid; i < kNumDSlots * 4; i += NT) {
         int c = i / kNumDSlots, s = i % kNumDSlots;
-        sh.g.rot[s][c] = S.brot[(c * kNumDSlots + s) * N + w];
+        sh.g.rot[s][c] = S.brot(c * kNumDSlots + s, w);
     }
     const int nw = S.numWalls[w], np = S.numPlanes[w];
     if (tid == 0) { sh.g.numWalls = nw; sh.g.numPlanes = np; sh.nPairs = 0; }
     for (int i = tid; i < nw * 4; i += NT) {
         int c = i / nw, k = i % nw;
-        sh.g.wall[k][c] = S.walls[(c * kMaxWalls + k) * N + w];
+        sh.g.wall[k][c] = S.walls(c * kMaxWalls + k, w);
     }
     for (int i = tid; i < np * 4; i += NT) {
         int c = i / np, p = i % np;
-        sh.g.plane[p][c] = S.planes[(c * kMaxPlanes + p) * N + w];
+        sh.g.plane[p][c] = S.planes(c * kMaxPlanes + p, w);
     }
-    for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther[i * N + w];
+    for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther(i, w);
 }
 
 HSD unsigned long long ray_key(float t, int id) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id; }

@@ -1,0 +1,900 @@
+// Physics step: movement / actions, PhysicsSystem::setupPhysicsStepTasks (src/sim.cpp:1162-1163; engine
+// source absent — DESIGN.md "Engine decisions") and the reward systems as ONE kernel, ONE WAVE PER OCTET.
+//
+// A workgroup is a single 64-lane wave that owns 8 consecutive worlds (an octet, hs_state.h) for the whole step.
+// The octet's working set — pose, previous pose, velocities and meta word of every body — is copied from its
+// contiguous blocks of the tiled columns into LDS once (struct OctRes, 20 KiB: 8 such waves share a CU's 160 KiB),
+// stays there through movement, the four XPBD substeps and the rewards, and is copied back once.  Nothing in the
+// step is shared between waves, so there is NO barrier between waves anywhere: a wave walks its own worlds
+// through the phases at its own pace while the other wave of its SIMD fills its stalls.  (The round-1 kernel ran
+// 64 worlds per 8-wave workgroup with a workgroup barrier after every phase: each of the ~26 phases of a step
+// then lasted as long as its slowest item among 64 worlds, and the average wave issued one instruction every
+// ~27 clocks.)
+//
+// Lane mappings inside the wave (L = lane):
+//   bodies     compact list of the octet's existing bodies in slot-major order, 64 per round (2 rounds for the
+//              benchmark's ~12 bodies per world): integrate, ground + wall contacts, velocity pass.  A body keeps
+//              its (round, lane) for the whole step, so its ground manifold lives in registers.
+//   worlds     8 lanes per world (world = L / 8): broadphase, body-body solve, rewards.
+//   pairs      2 lanes per candidate pair (L and L + 32): exact convex test.
+// Substep s:  [integrate s=0] -> detect -> sat -> dd<pos> -> body_pos -> dd<vel> -> body_vel (+ integrate s+1)
+// The Gauss-Seidel order and every rounding are the oracle's (joints, body-body in pair order, then per body:
+// ground, walls by static id).
+#pragma once
+#include "hs_state.h"
+#include "hs_rays.h"
+#include "hs_collide.h"
+#include "hs_solver.h"
+#include "hs_k_reset.h"
+
+namespace hs {
+
+constexpr int kPhysThreads = 64;                   // one wave
+constexpr int kPhysWorlds = kTile;                 // worlds per workgroup
+constexpr int kMaxBodyRounds = (kNumDSlots * kTile + 63) / 64;     // 3 (17 slots x 8 worlds = 136 bodies at most)
+constexpr int kMaxItems = kTile * (kMaxDDCand + kMaxSCand);        // convex-test items of an octet
+
+// ---- the octet's resident working set (LDS) ----
+// Every column is [row][world of the octet] exactly like its block in HBM (hs_state.h Col), so loading and storing
+// are linear copies, and a wave whose lanes are (slot, world) or (world, slot) pairs touches 64 distinct banks.
+struct alignas(16) OctRes {
+    float pos[3][kNumDSlots][kTile];
+    float rot[4][kNumDSlots][kTile];        // w, x, y, z
+    float ppos[3][kNumDSlots][kTile];       // pose at the start of the substep
+    float prot[4][kNumDSlots][kTile];
+    float lin[3][kNumDSlots][kTile];
+    float ang[3][kNumDSlots][kTile];
+    int meta[kNumDSlots][kTile];            // meta_pack(); 0 = empty slot
+    // Scratch of the broadphase / the convex tests.  The work list of the convex tests is written when the
+    // broadphase loops are over (the walls are dead by then) and lies beyond the clip buffers that the convex
+    // tests use, so both views can be live where they need to be.
+    union {
+        struct {
+            float lo[3][kNumDSlots][kTile], hi[3][kNumDSlots][kTile];   // hull AABBs: integrate -> detect
+            float wall[4][kMaxWalls][kTile];                            // cx, cy, hx, hy: staged by detect
+        } det;
+        struct {
+            float clip[kClipWords];                                     // polygon clipping of the convex tests
+            unsigned short items[kMaxItems + 32];                       // world << 6 | candidate (32+ = static); ramp items start at a multiple of 32
+        } sat;
+    } u;
+    unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 8
+    unsigned short scPair[kMaxSCand][kTile];    // body | static << 8  (static = wall index, 36 + plane index)
+    unsigned short scInfo[kNumDSlots][kTile];   // per body: first static candidate | count << 8
+    unsigned char bodies[kNumDSlots * kTile];   // compact list of existing bodies: slot << 3 | world
+    unsigned char actGL[kMaxAgents][kTile];     // grab / lock requests
+    unsigned char numWalls[kTile], numPlanes[kTile], ndd[kTile], nsc[kTile], seen[kTile], hasGrab[kTile];
+};
+static_assert(sizeof(OctRes) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
+static_assert(sizeof(((OctRes *)0)->u.sat) <= sizeof(((OctRes *)0)->u.det) &&
+              offsetof(OctRes, u.sat.items) >= offsetof(OctRes, u.det.wall), "items must not overlap the AABBs");
+
+// ---- accessors of the resident columns ----
+template <int C> HSD V3 rld3(const float (&a)[C][kNumDSlots][kTile], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g]}; }
+HSD Q rld4(const float (&a)[4][kNumDSlots][kTile], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g], a[3][slot][g]}; }
+HSD void rst3(float (&a)[3][kNumDSlots][kTile], int slot, int g, V3 v) { a[0][slot][g] = v.x; a[1][slot][g] = v.y; a[2][slot][g] = v.z; }
+HSD void rst4(float (&a)[4][kNumDSlots][kTile], int slot, int g, Q q) { a[0][slot][g] = q.w; a[1][slot][g] = q.x; a[2][slot][g] = q.y; a[3][slot][g] = q.z; }
+
+HSD void rbody_load(const OctRes &R, int g, int slot, BodyS &b) {
+    b.pos = rld3(R.pos, slot, g); b.rot = rld4(R.rot, slot, g);
+    b.ppos = rld3(R.ppos, slot, g); b.prot = rld4(R.prot, slot, g);
+    b.lin = rld3(R.lin, slot, g); b.ang = rld3(R.ang, slot, g);
+    const int m = R.meta[slot][g];
+    const bool dyn = m != 0 && meta_resp(m) == RESP_DYNAMIC;
+    b.invM = dyn ? obj_inv_mass(meta_obj(m)) : 0.f;
+    b.invI = dyn ? obj_inv_inertia(meta_obj(m)) : V3{0.f, 0.f, 0.f};
+    body_refresh_inertia(b);
+}
+HSD void rbody_store_pose(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.pos, slot, g, b.pos); rst4(R.rot, slot, g, b.rot); }
+HSD void rbody_store_vel(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.lin, slot, g, b.lin); rst3(R.ang, slot, g, b.ang); }
+HSD void derive_velocity(BodyS &b) {
+    const float h = kSubstepH;
+    b.lin = (b.pos - b.ppos) * (1.f / h);
+    Q dq = qmul(b.rot, qinv(b.prot));
+    V3 wv = V3{dq.x, dq.y, dq.z} * (2.f / h);
+    b.ang = dq.w >= 0.f ? wv : -wv;
+}
+
+// Everything of the LDS that one phase wrote is read by other lanes in the next: one wave, so program order is
+// enough for the hardware (LDS operations of a wave execute in order) — this keeps the compiler from moving them.
+HSD void wave_sync() { __syncthreads(); }
+
+// Geometry view of one world of the octet for trace_ray (hs_rays.h): bodies from the resident columns, walls and
+// the (at most 3) planes from global memory (the rays of the physics kernel — lock / grab, seeker -> hider line
+// of sight — are few; the lidar / visibility rays are k_observe's).
+struct ResGeom {
+    const OctRes &R; const SimState &S; int g; int w;
+    HSD int g_meta(int i) const { return R.meta[i][g]; }
+    HSD V3 g_pos(int i) const { return rld3(R.pos, i, g); }
+    HSD Q g_rot(int i) const { return rld4(R.rot, i, g); }
+    HSD int g_num_walls() const { return R.numWalls[g]; }
+    HSD float g_wall(int k, int c) const { return S.walls(c * kMaxWalls + k, w); }
+    HSD int g_num_planes() const { return R.numPlanes[g]; }
+    HSD float g_plane(int p, int c) const { return S.planes(c * kMaxPlanes + p, w); }
+};
+
+// What a body's lane keeps in registers for the whole step: which body it is, the agent's force / torque, and the
+// ground-plane manifold of the current substep (up to 4 deepest vertices, hs_collide.h ground_manifold).
+struct BodyReg {
+    int slot, g;             // -1: no body in this (round, lane)
+    int meta;
+    V3 force; float torque;  // ExternalForce / ExternalTorque.z (agents)
+    int np, vidx;            // ground manifold: contact count, 3 bits of vertex index per contact
+    float off[4], lam[4];    // plane offsets, accumulated normal multipliers
+};
+
+// ------------------------------------------------------------------------------------------
+// Linear copies between the octet's blocks of the tiled columns and LDS.
+template <typename T, int ROWS>
+HSD void copy_in(T *dst, const Col<T, ROWS> &col, int o) {
+    const T *src = col.octet(o);
+    for (int i = threadIdx.x; i < ROWS * kTile; i += 64) dst[i] = src[i];
+}
+template <typename T, int ROWS>
+HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
+    T *dst = col.octet(o);
+    for (int i = threadIdx.x; i < ROWS * kTile; i += 64) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Start of a substep for one body: remember the pose, semi-implicit Euler step (gravity, agent force and
+// torque, gyroscopic term), refresh the hull AABB and the ground-plane manifold.
+HSD void integrate_body(const SimState &S, OctRes &R, BodyReg &b, V3 pos, Q rot, V3 lin, V3 ang) {
+    const int slot = b.slot, g = b.g, meta = b.meta;
+    const int obj = meta_obj(meta);
+    rst3(R.ppos, slot, g, pos); rst4(R.prot, slot, g, rot);
+    if (meta_resp(meta) == RESP_DYNAMIC) {
+        const float h = kSubstepH;
+        const float invM = obj_inv_mass(obj);
+        const V3 invI = obj_inv_inertia(obj);
+        lin = lin + (b.force * invM + V3{0.f, 0.f, kGravityZ}) * h;
+        pos = pos + lin * h;
+        Q qi = qinv(rot);
+        V3 wloc = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, b.torque});
+        const V3 I = obj_inertia(obj);            // 1 / invI per axis, 0 where invI is 0
+        V3 Iw = mulc(I, wloc);
+        wloc = wloc + mulc(invI, tl - cross(wloc, Iw)) * h;
+        ang = qrot(rot, wloc);
+        rot = quat_add_rotation(rot, ang * h);
+        rst3(R.pos, slot, g, pos); rst4(R.rot, slot, g, rot);
+        rst3(R.lin, slot, g, lin); rst3(R.ang, slot, g, ang);
+    }
+    V3 lo, hi;
+    const HullRef hb = hull_ref_body(obj, pos, rot);
+    hull_aabb(hb, &lo, &hi);
+    rst3(R.u.det.lo, slot, g, lo); rst3(R.u.det.hi, slot, g, hi);
+    // ground plane (plane 0) manifold at the integrated pose
+    b.np = 0; b.vidx = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.lam[j] = 0.f;
+    if (meta_resp(meta) == RESP_DYNAMIC && R.numPlanes[g] >= 1) {
+        const int w = S.wbeg + g;
+        const V3 pn = {S.planes(0 * kMaxPlanes, w), S.planes(1 * kMaxPlanes, w), S.planes(2 * kMaxPlanes, w)};
+        b.np = ground_manifold(hb, pn, S.planes(3 * kMaxPlanes, w), &b.vidx, b.off);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// All-pairs AABB candidates (<= 17 bodies, <= 36 walls per world: no BVH), 8 lanes per world: lane l of a world
+// owns body slots l, l + 8, l + 16.  Also builds the octet's work list of convex tests.  Returns the number of
+// box-only items in .x and of items that involve a ramp (wedge hull) in .y; the ramp items start at the next
+// multiple of 32 so that most rounds of the convex test run the box code only.
+struct ItemCounts { int nbox, nwedge; };
+HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
+    constexpr int G = 8, JB = (kNumDSlots + G - 1) / G;
+    const int L = threadIdx.x, g = L / G, l = L % G;
+    const int o = blockIdx.x;
+    // the octet's walls -> LDS (one contiguous block; rows beyond a world's count are never read)
+    {
+        const float4 *src = (const float4 *)S.walls.octet(o);
+        float4 *dst = (float4 *)&R.u.det.wall[0][0][0];
+        for (int i = L; i < 4 * kMaxWalls * kTile / 4; i += 64) dst[i] = src[i];
+    }
+    wave_sync();
+    const int nwl = R.numWalls[g], npl = R.numPlanes[g];
+    int tot_items = 0;
+    unsigned dd_mask[JB] = {}; unsigned long long s_mask[JB] = {};
+    int bdd[JB] = {}, bsc[JB] = {}, add[JB] = {}, asc[JB] = {};
+    bool have[JB], dynamic[JB]; V3 lo[JB], hi[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        const int slot = l + jb * G;
+        const int meta = slot < NS ? R.meta[slot][g] : 0;
+        have[jb] = meta != 0;
+        dynamic[jb] = have[jb] && meta_resp(meta) == RESP_DYNAMIC;
+        lo[jb] = {0.f, 0.f, 0.f}; hi[jb] = {0.f, 0.f, 0.f};
+        if (have[jb]) { lo[jb] = rld3(R.u.det.lo, slot, g); hi[jb] = rld3(R.u.det.hi, slot, g); }
+    }
+    // The loops run over the OTHER body / the wall, each read from LDS once and tested against all of the lane's slots.
+    for (int j = 1; j < NS; ++j) {
+        const int mj = R.meta[j][g];
+        if (mj == 0) continue;
+        const bool dynj = meta_resp(mj) == RESP_DYNAMIC;
+        const V3 loj = rld3(R.u.det.lo, j, g), hij = rld3(R.u.det.hi, j, g);
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) {
+            if (have[jb] && l + jb * G < j && (dynamic[jb] || dynj) &&
+                lo[jb].x <= hij.x && loj.x <= hi[jb].x && lo[jb].y <= hij.y && loj.y <= hi[jb].y &&
+                lo[jb].z <= hij.z && loj.z <= hi[jb].z) dd_mask[jb] |= 1u << j;
+        }
+    }
+    for (int k = 0; k < nwl; ++k) {
+        const float cx = R.u.det.wall[0][k][g], cy = R.u.det.wall[1][k][g], hx = R.u.det.wall[2][k][g], hy = R.u.det.wall[3][k][g];
+        const float wx0 = cx - hx, wx1 = cx + hx, wy0 = cy - hy, wy1 = cy + hy;
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) {
+            if (dynamic[jb] && lo[jb].x <= wx1 && wx0 <= hi[jb].x && lo[jb].y <= wy1 && wy0 <= hi[jb].y &&
+                lo[jb].z <= 2.5f && 0.f <= hi[jb].z) s_mask[jb] |= 1ull << k;
+        }
+    }
+    // candidate slots in the world's lists: prefix sums in body-slot order (slots l of all lanes, then l + 8, ...),
+    // i.e. the oracle's candidate order — so even the pairs dropped beyond the capacity are the oracle's
+    int tot_dd = 0, tot_sc = 0;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        if (dynamic[jb]) for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
+        const int cdd = __popc(dd_mask[jb]), csc = __popcll(s_mask[jb]);
+        int in_dd = cdd, in_sc = csc;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const int y0 = __shfl_up(in_dd, d, G), y1 = __shfl_up(in_sc, d, G);
+            if (l >= d) { in_dd += y0; in_sc += y1; }
+        }
+        bdd[jb] = tot_dd + in_dd - cdd; bsc[jb] = tot_sc + in_sc - csc;
+        tot_dd += __shfl(in_dd, G - 1, G); tot_sc += __shfl(in_sc, G - 1, G);
+        add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
+        asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
+        tot_items += add[jb] + asc[jb];
+        if (add[jb] != cdd || asc[jb] != csc) {      // beyond the capacity: dropped (as the CPU restatement does), and counted
+            if (add[jb] != cdd) atomicAdd(&S.status[0], cdd - add[jb]);
+            if (asc[jb] != csc) atomicAdd(&S.status[1], csc - asc[jb]);
+            *S.hostFlag = 1;
+        }
+    }
+    // ---- the octet's work list: box-only items from the front, items with a ramp behind them (from a multiple of 32)
+    int n_wedge = 0;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        const int slot = l + jb * G;
+        const bool ramp = slot >= kRampSlot0 && slot < kRampSlot0 + kMaxRamps;
+        if (ramp) n_wedge += add[jb] + asc[jb];
+        else { unsigned mm = dd_mask[jb]; for (int i = 0; mm && i < add[jb]; ++i) { const int j = __ffs(mm) - 1; mm &= mm - 1; n_wedge += (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps) ? 1 : 0; } }
+    }
+    const int n_box = tot_items - n_wedge;
+    int inc_box = n_box, inc_wedge = n_wedge;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y0 = __shfl_up(inc_box, d), y1 = __shfl_up(inc_wedge, d);
+        if (L >= d) { inc_box += y0; inc_wedge += y1; }
+    }
+    ItemCounts ic;
+    ic.nbox = __shfl(inc_box, 63); ic.nwedge = __shfl(inc_wedge, 63);
+    const int wedge0 = (ic.nbox + 31) / 32 * 32;
+    int ibox = inc_box - n_box, iwedge = wedge0 + inc_wedge - n_wedge;
+    wave_sync();                          // every lane is done with the walls: the work list may overwrite them
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+        const int slot = l + jb * G;
+        const bool ramp = slot >= kRampSlot0 && slot < kRampSlot0 + kMaxRamps;
+        unsigned mm = dd_mask[jb]; int i = 0;
+        while (mm && i < add[jb]) {
+            const int j = __ffs(mm) - 1; mm &= mm - 1;
+            R.ddPair[bdd[jb] + i][g] = (unsigned short)(slot | (j << 8));
+            const unsigned short item = (unsigned short)((g << 6) | (bdd[jb] + i));
+            if (ramp || (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps)) R.u.sat.items[iwedge++] = item; else R.u.sat.items[ibox++] = item;
+            ++i;
+        }
+        // oracle order inside a body: extra planes first, then walls by index; the body's candidates
+        // occupy the contiguous range [bsc, bsc + asc) of the world's list
+        unsigned long long sm = (s_mask[jb] >> kMaxWalls) | (s_mask[jb] << (64 - kMaxWalls) >> (64 - kMaxWalls) << kMaxPlanes); i = 0;
+        while (sm && i < asc[jb]) {
+            const int bit = __ffsll((long long)sm) - 1; sm &= sm - 1;
+            const int k = bit < kMaxPlanes ? kMaxWalls + bit : bit - kMaxPlanes;
+            R.scPair[bsc[jb] + i][g] = (unsigned short)(slot | (k << 8));
+            const unsigned short item = (unsigned short)((g << 6) | 32 | (bsc[jb] + i));
+            if (ramp) R.u.sat.items[iwedge++] = item; else R.u.sat.items[ibox++] = item;
+            ++i;
+        }
+        if (slot < NS) R.scInfo[slot][g] = (unsigned short)(asc[jb] > 0 ? (bsc[jb] | (asc[jb] << 8)) : 0);
+    }
+    if (l == 0) { R.ndd[g] = (unsigned char)min(tot_dd, kMaxDDCand); R.nsc[g] = (unsigned char)min(tot_sc, kMaxSCand); }
+    wave_sync();
+    return ic;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact convex tests.  Two lanes per item: lane L < 32 and lane L + 32 run the test of the same pair together
+// (collide_hulls); the low lane owns the clip scratch and writes the manifold.
+HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
+    static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
+    const int wedge0 = (ic.nbox + 31) / 32 * 32;
+    const int total = ic.nwedge > 0 ? wedge0 + ic.nwedge : ic.nbox;
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= kClipLanes;
+    const ClipBuf cb = {R.u.sat.clip, lane & (kClipLanes - 1)};
+    for (int it = lane & (kClipLanes - 1); it < total; it += kClipLanes) {
+        if (it >= ic.nbox && it < wedge0) continue;
+        const int item = R.u.sat.items[it];
+        const int g = item >> 6, idx = item & 63;
+        const int w = S.wbeg + g;
+        const bool isdd = idx < 32;
+        const int kk = idx & 31;
+        const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
+        const int a = pair & 0xff, bsel = pair >> 8;
+        ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
+        ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
+        const int oa = meta_obj(R.meta[a][g]);
+        const V3 pa = rld3(R.pos, a, g);
+        const Q qa = rld4(R.rot, a, g);
+        const HullRef ha = hull_ref_body(oa, pa, qa);
+        RawManifold raw;
+        if (!hi) { if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0; }
+        if (!isdd && bsel >= kMaxWalls) {
+            const int p = bsel - kMaxWalls;
+            const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
+            if (!hi && collide_hull_plane(ha, pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
+                ManS m;
+                m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
+                m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
+                m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = j < raw.np;
+                    st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
+                    m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
+                }
+                wsSC[kk] = m;
+            }
+            continue;
+        }
+        int ob; V3 pb = {0.f, 0.f, 0.f}; Q qb = {1.f, 0.f, 0.f, 0.f};
+        HullRef hb;
+        if (isdd) {
+            ob = meta_obj(R.meta[bsel][g]); pb = rld3(R.pos, bsel, g); qb = rld4(R.rot, bsel, g);
+            hb = hull_ref_body(ob, pb, qb);
+        } else {
+            ob = OBJ_WALL;      // (the staged walls share their LDS with the clip buffers: from global memory here)
+            hb = hull_ref_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
+                               S.walls(2 * kMaxWalls + bsel, w), S.walls(3 * kMaxWalls + bsel, w));
+        }
+        if (!collide_hulls(ha, hb, cb, raw, hi)) continue;
+        const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
+        const Q qai = qinv(qa);
+        if (isdd) {
+            ManDD m;
+            m.a = a; m.b = bsel; m.np = raw.np; m.muS = muS; m.muD = muD;
+            st3(m.n, raw.n);
+            const Q qbi = qinv(qb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = j < raw.np;
+                st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
+                m.lam[j] = 0.f;
+            }
+            wsDD[kk] = m;
+        } else {
+            ManS m;
+            m.np = raw.np; m.muS = muS; m.muD = muD; m.pad[0] = 0.f; m.pad[1] = 0.f;
+            st3(m.n, raw.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = j < raw.np;
+                st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
+            }
+            wsSC[kk] = m;
+        }
+    }
+    wave_sync();          // the manifolds (global memory) are complete for the lanes that solve them
+}
+
+// Fixed grab joint on two loaded bodies (sim.cpp:343-356): angular alignment, then anchor coincidence.
+HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep, V3 r1, Q attach1) {
+    {
+        Q qa = qmul(A.rot, attach1), qb = qmul(B.rot, attach2);
+        Q dq = qmul(qa, qinv(qb));
+        V3 dphi = {2.f * dq.x, 2.f * dq.y, 2.f * dq.z};
+        if (dq.w < 0.f) dphi = -dphi;
+        float th2 = len2(dphi);
+        if (th2 > 1e-12f) {
+            float th = sqrtf(th2);
+            V3 ax = dphi * (1.f / th);
+            float wA = dot(ax, sym_mul(A.Iw, ax));
+            float wB = dot(ax, sym_mul(B.Iw, ax));
+            float ws = wA + wB;
+            if (ws > 0.f) {
+                V3 p = ax * (th / ws);
+                A.rot = quat_add_rotation(A.rot, -apply_inv_inertia(A, p));
+                B.rot = quat_add_rotation(B.rot, apply_inv_inertia(B, p));
+            }
+        }
+    }
+    {
+        V3 anchorA = r1 + V3{0.f, sep, 0.f};
+        V3 rAw = qrot(A.rot, anchorA), rBw = qrot(B.rot, r2);
+        V3 dx = (A.pos + rAw) - (B.pos + rBw);
+        float c2 = len2(dx);
+        if (c2 > 1e-12f) {
+            float c = sqrtf(c2);
+            V3 n = dx * (1.f / c);
+            float ws = gen_inv_mass(A, rAw, n) + gen_inv_mass(B, rBw, n);
+            if (ws > 0.f) apply_pos_impulse<true>(A, rAw, B, rBw, n * (c / ws));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Body-body manifolds (and grab joints), 8 lanes per world, all 8 worlds of the octet at once.  The oracle solves a
+// world's manifolds one after the other in (i<j) pair order; manifolds that share no body commute exactly, so lane q
+// takes the q-th accepted manifold of the sorted order and runs as soon as no EARLIER manifold that is still
+// pending touches one of its bodies.  Disjoint pairs are solved in one round instead of one after the other; the
+// result is bit-identical to the sequential order.
+template <bool POS>
+HSD void phase_dd(const SimState &S, OctRes &R) {
+    constexpr int GL = 8;
+    const int L = threadIdx.x, g = L / GL, q = L % GL;
+    const int gbit0 = g * GL;                                     // first lane of this group in the wave
+    const int w = S.wbeg + g;
+    const int ndd = R.ndd[g];
+    const bool grab = R.hasGrab[g] != 0;
+    if (__ballot(ndd > 0 || (POS && grab)) == 0ull) return;        // nothing to do in the whole octet
+    if (POS && grab && q == 0) {
+        const int teams = S.teams[w];
+        for (int a = 0; a < kMaxAgents; ++a) {
+            if (!team_agent_active(teams, a)) continue;
+            const int other = S.grabOther(a, w);
+            if (other < 0) continue;
+            BodyS A, B;
+            rbody_load(R, g, kAgentSlot0 + a, A); rbody_load(R, g, other, B);
+            float gd[kGrabWords];
+#pragma unroll
+            for (int c = 0; c < kGrabWords; ++c) gd[c] = S.grabData(c * kMaxAgents + a, w);
+            solve_grab_joint_bodies(A, B, {gd[0], gd[1], gd[2]}, {gd[3], gd[4], gd[5], gd[6]}, gd[7],
+                                    {gd[8], gd[9], gd[10]}, {gd[11], gd[12], gd[13], gd[14]});
+            rbody_store_pose(R, g, kAgentSlot0 + a, A); rbody_store_pose(R, g, other, B);
+        }
+    }
+    wave_sync();
+    ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
+    // keys of the accepted candidates, kMaxDDCand = 16: lane q inspects candidates q and q+8
+    int key0 = 0x7fffffff, key1 = 0x7fffffff;
+    if (q < ndd && wsDD[q].np > 0) { const int p = R.ddPair[q][g]; key0 = ((p & 0xff) << 8) | (p >> 8); }
+    if (q + GL < ndd && wsDD[q + GL].np > 0) { const int p = R.ddPair[q + GL][g]; key1 = ((p & 0xff) << 8) | (p >> 8); }
+    // rank of every accepted candidate in sorted key order (keys are unique: distinct pairs)
+    int rank0 = 0, rank1 = 0, nacc = 0;
+#pragma unroll
+    for (int p = 0; p < GL; ++p) {
+        const int k0 = __shfl(key0, gbit0 + p), k1 = __shfl(key1, gbit0 + p);
+        rank0 += (k0 < key0) + (k1 < key0); rank1 += (k0 < key1) + (k1 < key1);
+        nacc += (k0 != 0x7fffffff) + (k1 != 0x7fffffff);
+    }
+    for (int base = 0; base < kMaxDDCand; base += GL) {
+        if (__ballot(base < nacc) == 0ull) break;
+        // lane q takes the manifold of rank base+q: find which lane/slot holds it
+        int mine = -1;
+#pragma unroll
+        for (int p = 0; p < GL; ++p) {
+            const int r0 = __shfl(rank0, gbit0 + p), r1 = __shfl(rank1, gbit0 + p);
+            const int k0 = __shfl(key0, gbit0 + p), k1 = __shfl(key1, gbit0 + p);
+            if (k0 != 0x7fffffff && r0 == base + q) mine = p;
+            if (k1 != 0x7fffffff && r1 == base + q) mine = p + GL;
+        }
+        int ma = -1, mb = -1;
+        ManDD m;
+        if (mine >= 0) { m = wsDD[mine]; ma = m.a; mb = m.b; }
+        bool pending = mine >= 0;
+        while (true) {
+            const unsigned long long pend_mask = __ballot(pending);
+            if (pend_mask == 0ull) break;
+            bool ready = pending;
+#pragma unroll
+            for (int p = 0; p < GL; ++p) {
+                const int pa = __shfl(ma, gbit0 + p), pb = __shfl(mb, gbit0 + p);
+                const bool ppend = (pend_mask >> (gbit0 + p)) & 1ull;
+                if (p < q && ppend && (pa == ma || pa == mb || pb == ma || pb == mb)) ready = false;
+            }
+            if (ready) {
+                BodyS Ab, Bb;
+                rbody_load(R, g, m.a, Ab); rbody_load(R, g, m.b, Bb);
+                const V3 n = ld3(m.n);
+                if (POS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < m.np) wsDD[mine].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+                    rbody_store_pose(R, g, m.a, Ab); rbody_store_pose(R, g, m.b, Bb);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
+                    rbody_store_vel(R, g, m.a, Ab); rbody_store_vel(R, g, m.b, Bb);
+                }
+                pending = false;
+            }
+            wave_sync();                  // later rounds must see the poses / velocities just written
+        }
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------
+// Static contacts of one body, in the oracle's order: ground manifold (registers), then the body's other static
+// candidates (extra planes, walls by index); then the velocities of the substep from the pose change.
+HSD void body_pos_item(const SimState &S, OctRes &R, BodyReg &b) {
+    const int slot = b.slot, g = b.g, meta = b.meta;
+    if (meta_resp(meta) != RESP_DYNAMIC) return;
+    const int w = S.wbeg + g;
+    const int obj = meta_obj(meta);
+    const int sci = R.scInfo[slot][g];
+    BodyS me, none;
+    rbody_load(R, g, slot, me);
+    if (b.np > 0) {
+        const V3 gn = -V3{S.planes(0 * kMaxPlanes, w), S.planes(1 * kMaxPlanes, w), S.planes(2 * kMaxPlanes, w)};
+        const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < b.np) b.lam[j] += solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7),
+                                                                  V3{0.f, 0.f, 0.f}, b.off[j], gmuS);
+    }
+    if (sci != 0) {
+        ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
+        const int bsc = sci & 0xff, asc = sci >> 8;
+#pragma unroll 1
+        for (int k = bsc; k < bsc + asc; ++k) {       // the body's candidates, already in solve order
+            ManS m = wsSC[k];
+            if (m.np <= 0) continue;
+            body_refresh_inertia(me);
+            const V3 n = ld3(m.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < m.np) wsSC[k].lam[j] = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+        }
+    }
+    if (b.np > 0 || sci != 0) rbody_store_pose(R, g, slot, me);
+    derive_velocity(me);
+    rbody_store_vel(R, g, slot, me);
+}
+
+// Velocity pass over a body's static contacts; with NEXT, also the start of the following substep for the body,
+// integrated from registers.
+template <bool NEXT>
+HSD void body_vel_item(const SimState &S, OctRes &R, BodyReg &b) {
+    const int slot = b.slot, g = b.g, meta = b.meta;
+    if (meta_resp(meta) != RESP_DYNAMIC) {
+        if (NEXT) integrate_body(S, R, b, rld3(R.pos, slot, g), rld4(R.rot, slot, g), V3{0.f, 0.f, 0.f}, V3{0.f, 0.f, 0.f});
+        return;
+    }
+    const int w = S.wbeg + g;
+    const int sci = R.scInfo[slot][g];
+    if (b.np == 0 && sci == 0) {
+        if (NEXT) integrate_body(S, R, b, rld3(R.pos, slot, g), rld4(R.rot, slot, g), rld3(R.lin, slot, g), rld3(R.ang, slot, g));
+        return;
+    }
+    const int obj = meta_obj(meta);
+    BodyS me, none;
+    rbody_load(R, g, slot, me);
+    if (b.np > 0) {
+        const V3 gn = -V3{S.planes(0 * kMaxPlanes, w), S.planes(1 * kMaxPlanes, w), S.planes(2 * kMaxPlanes, w)};
+        const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < b.np) solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7), V3{0.f, 0.f, 0.f},
+                                                      b.lam[j], gmuD);
+    }
+    if (sci != 0) {
+        const ManS *const wsSC = (const ManS *)S.wsSC + (size_t)w * kMaxSCand;
+        const int bsc = sci & 0xff, asc = sci >> 8;
+#pragma unroll 1
+        for (int k = bsc; k < bsc + asc; ++k) {
+            const ManS m = wsSC[k];
+            if (m.np <= 0) continue;
+            body_refresh_inertia(me);
+            const V3 n = ld3(m.n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
+        }
+    }
+    if (NEXT) integrate_body(S, R, b, me.pos, me.rot, me.lin, me.ang);
+    else rbody_store_vel(R, g, slot, me);
+}
+
+// ------------------------------------------------------------------------------------------
+// actionSystem (sim.cpp:270-370) for one world, agents in interface order, run by ONE lane: lock / grab ray casts
+// against the resident geometry, joint create / destroy.  Meta words change in LDS (copied back at the end of
+// the launch); the joint table lives in global memory.
+HSD void action_system(const SimState &S, OctRes &R, int g, int A_, int teams) {
+    const int w = S.wbeg + g;
+    const ResGeom geom = {R, S, g, w};
+    for (int i = 0; i < A_; ++i) {
+        const int fl = R.actGL[i][g];
+        if (fl == 0) continue;
+        const int type = team_agent_type(teams, i);
+        const int slot = kAgentSlot0 + i;
+        const V3 mpos = geom.g_pos(slot);
+        const Q mrot = geom.g_rot(slot);
+        if (fl & 2) {   // lock
+            float t; V3 o = mpos + V3{0.f, 0.f, 0.5f};
+            int hit = trace_ray(geom, o, qrot(mrot, {0.f, 1.f, 0.f}), 2.5f, &t);
+            if (hit >= 0 && hit < kNumDSlots) {
+                const int m = R.meta[hit][g];
+                const int obj = meta_obj(m), resp = meta_resp(m), owner = meta_owner(m);
+                if (resp == RESP_STATIC) {
+                    if ((type == AGENT_SEEKER && owner == OWNER_SEEKER) || (type == AGENT_HIDER && owner == OWNER_HIDER))
+                        R.meta[hit][g] = meta_pack(obj, RESP_DYNAMIC, OWNER_NONE);
+                } else if (owner == OWNER_NONE) {
+                    R.meta[hit][g] = meta_pack(obj, RESP_STATIC, type == AGENT_HIDER ? OWNER_HIDER : OWNER_SEEKER);
+                }
+            }
+        }
+        if (fl & 1) {   // grab
+            if (S.grabOther(i, w) >= 0) {
+                S.grabOther(i, w) = -1;
+            } else {
+                float t; V3 o = mpos + V3{0.f, 0.f, 0.5f};
+                V3 dir = qrot(mrot, {0.f, 1.f, 0.f});
+                int hit = trace_ray(geom, o, dir, 2.5f, &t);
+                if (hit >= 0 && hit < kNumDSlots) {
+                    const int m = R.meta[hit][g];
+                    if (meta_owner(m) == OWNER_NONE && meta_resp(m) == RESP_DYNAMIC) {
+                        V3 hit_pos = o + dir * t;
+                        Q erot = geom.g_rot(hit);
+                        V3 r2 = qrot(qinv(erot), hit_pos - geom.g_pos(hit));
+                        Q at2 = qnormalize(qmul(qinv(erot), mrot));
+                        S.grabOther(i, w) = hit;
+                        const float gd[kGrabWords] = {r2.x, r2.y, r2.z, at2.w, at2.x, at2.y, at2.z, t - 1.25f,
+                                                      0.f, 1.25f, 0.5f,            // r1 = 1.25 fwd + 0.5 up (sim.cpp:343-344)
+                                                      1.f, 0.f, 0.f, 0.f};         // attachRot1 = identity
+#pragma unroll
+                        for (int c = 0; c < kGrabWords; ++c) S.grabData(c * kMaxAgents + i, w) = gd[c];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Before the substeps: movementSystem | instantMovementSystem (sim.cpp:202-254) and actionSystem (:270-370).
+// A lane per (agent, world) maps the action row to a force; a lane per world then runs the action system for the
+// worlds in which an agent locks or grabs (scripts/benchmark.py never does, scripts/jax_train.py does all the time).
+HSD void phase_pre(const SimState &S, OctRes &R) {
+    const int A_ = S.A, L = threadIdx.x;
+    const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
+    bool need_action = false;
+    if (L < kMaxAgents * kTile) {
+        const int agent = L / kTile, g = L % kTile;
+        const int w = S.wbeg + g;
+        int fl = 0;
+        if (agent < A_ && g < S.wcnt) {
+            const int teams = S.teams[w], step = S.curEpisodeStep[w];
+            const bool active = team_agent_active(teams, agent) != 0;
+            const int type = team_agent_type(teams, agent);
+            if (active && !(type == AGENT_SEEKER && step < kNumPrepSteps - 1)) {
+                int32_t *act_row = S.xAction + (w * A_ + agent) * 5;
+                const int ax = act_row[0], ay = act_row[1], ar = act_row[2], ag = act_row[3], al = act_row[4];
+                float fx, fy, tz;
+                if (instant) { fx = 400.f * (float)(ax - 2); fy = 400.f * (float)(ay - 2); tz = 120.f * (float)(ar - 2); }
+                else { fx = 12.f * (float)(ax - 5); fy = 12.f * (float)(ay - 5); tz = 3.f * (float)(ar - 5); }
+                V3 f = qrot(rld4(R.rot, kAgentSlot0 + agent, g), {fx, fy, 0.f});
+                S.aforce(0 * kMaxAgents + agent, w) = f.x; S.aforce(1 * kMaxAgents + agent, w) = f.y;
+                S.aforce(2 * kMaxAgents + agent, w) = f.z; S.aforce(3 * kMaxAgents + agent, w) = tz;
+                fl = (ag == 1 ? 1 : 0) | (al == 1 ? 2 : 0);
+                act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;   // sim.cpp:365-369
+            }
+        }
+        R.actGL[agent][g] = (unsigned char)fl;
+        need_action = fl != 0;
+    }
+    const bool any = __ballot(need_action) != 0ull;
+    wave_sync();                          // actGL and the forces (global memory) are in place
+    if (any && L < S.wcnt) {              // one lane per world: the ray casts of a world are sequential
+        bool want = false;
+        for (int a = 0; a < A_; ++a) want |= R.actGL[a][L] != 0;
+        if (want) action_system(S, R, L, A_, S.teams[S.wbeg + L]);
+    }
+    // worlds with a grab joint take part in the body-body phase of every substep
+    if (L < kTile) {
+        bool grab = false;
+        if (L < S.wcnt) for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther(a, S.wbeg + L) >= 0;
+        R.hasGrab[L] = grab ? 1 : 0;
+    }
+    wave_sync();
+}
+
+// After the substeps: agentZeroVelSystem (sim.cpp:258-268), rewardsVisSystem (:763-804),
+// outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893).  8 lanes per world.
+HSD void phase_post(const SimState &S, OctRes &R) {
+    constexpr int G = 8;
+    const int L = threadIdx.x, g = L / G, l = L % G;
+    const int w = S.wbeg + g;
+    const int A_ = S.A;
+    const bool wok = g < S.wcnt;
+    const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
+    int teams = 0, step = 0, counts = 0;
+    if (wok) {
+        teams = S.teams[w]; step = S.curEpisodeStep[w]; counts = S.counts[w];
+        if (l == 0) R.seen[g] = 0;
+        if (instant && l < kMaxAgents && R.meta[kAgentSlot0 + l][g] != 0) {
+            const int slot = kAgentSlot0 + l;
+            R.lin[0][slot][g] = 0.f; R.lin[1][slot][g] = 0.f;
+            R.lin[2][slot][g] = fminf(R.lin[2][slot][g], 0.f);
+            rst3(R.ang, slot, g, V3{0.f, 0.f, 0.f});
+        }
+    }
+    wave_sync();
+    // The seen flag feeds the reward (from episode step 95 on) and the episode result (from 96 on); the reset overwrites
+    // hiderTeamReward every step, so during the preparation phase the rays would change nothing anyone can read.
+    for (int pr = l; wok && step >= kNumPrepSteps - 1 && pr < 9; pr += G) {      // (seeker, hider) pairs
+        const int si = pr / 3, hi_ = pr % 3;
+        if (si < cnt_seekers(counts) && hi_ < cnt_hiders(counts)) {
+            const ResGeom geom = {R, S, g, w};
+            const int ss = kAgentSlot0 + team_seeker(teams, si), hs_ = kAgentSlot0 + team_hider(teams, hi_);
+            const V3 spos = geom.g_pos(ss);
+            const V3 fwd = qrot(geom.g_rot(ss), {0.f, 1.f, 0.f});
+            V3 to = geom.g_pos(hs_) - spos;
+            float c = dot(normalize(to), fwd);
+            if (!(c < kCosFovHalf)) {
+                float t;
+                if (trace_ray(geom, spos, to, 1.f, &t) == hs_) R.seen[g] = 1;   // every writer stores the same value
+            }
+        }
+    }
+    wave_sync();
+    if (!wok) return;
+    float hider_reward = S.hiderTeamReward[w];
+    if (R.seen[g]) hider_reward = -1.f;
+    if (l < A_ && team_agent_active(teams, l)) {
+        const int agent = l, slot = kAgentSlot0 + agent, row = w * A_ + agent;
+        if (step == 0) S.xDone[row] = 0;
+        if (step < kNumPrepSteps - 1) {
+            S.xReward[row] = 0.f;
+        } else {
+            if (step == kEpisodeLen - 1) S.xDone[row] = 1;
+            float r = hider_reward;
+            if (team_agent_type(teams, agent) == AGENT_SEEKER) r *= -1.f;
+            if (fabsf(R.pos[0][slot][g]) >= 18.f || fabsf(R.pos[1][slot][g]) >= 18.f) r -= 10.f;
+            S.xReward[row] = r;
+        }
+    }
+    if (l == 0) {
+        float *res = S.xEpisodeResult + w * 2;
+        int s0 = S.runningScores(0, w), s1 = S.runningScores(1, w);
+        if (step == 0) { res[0] = 0.f; res[1] = 0.f; s0 = 0; s1 = 0; }
+        if (step >= kNumPrepSteps) {
+            const bool hidden = hider_reward == 1.f;
+            const bool sf = cnt_seekers_first(counts) != 0;
+            const int win = hidden ? (sf ? 1 : 0) : (sf ? 0 : 1);
+            if (win == 0) s0 += 1; else s1 += 1;
+        }
+        if (step == kEpisodeLen - 1) {
+            if (s0 > s1) { res[0] = 1.f; res[1] = 0.f; }
+            else if (s0 < s1) { res[0] = 0.f; res[1] = 1.f; }
+            else { res[0] = 0.5f; res[1] = 0.5f; }
+        }
+        S.runningScores(0, w) = s0; S.runningScores(1, w) = s1;
+        S.hiderTeamReward[w] = hider_reward;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
+    __shared__ OctRes R;
+    const int L = threadIdx.x, o = blockIdx.x;
+    S.wbeg = o * kTile;
+    S.wcnt = min(kTile, S.N - S.wbeg);
+    const int NS = kAgentSlot0 + S.A;                 // body slots in use
+#ifdef HS_PHASE_TIMING
+    // development aid: wall-clock ticks (100 MHz) per phase of every octet -> S.phaseTicks[octet][10]
+    long long tk = wall_clock64(); long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HS_TICK(i) { const long long now_ = wall_clock64(); acc[i] += now_ - tk; tk = now_; }
+#else
+#define HS_TICK(i)
+#endif
+    // ---- the octet's columns -> LDS (the blocks are contiguous; worlds beyond N are zero padding = empty slots)
+    copy_in(&R.pos[0][0][0], S.bpos, o); copy_in(&R.rot[0][0][0], S.brot, o);
+    copy_in(&R.lin[0][0][0], S.blin, o); copy_in(&R.ang[0][0][0], S.bang, o);
+    copy_in(&R.meta[0][0], S.bmeta, o);
+    if (L < kTile) {
+        const bool ok = L < S.wcnt;
+        R.numWalls[L] = ok ? (unsigned char)S.numWalls[S.wbeg + L] : 0;
+        R.numPlanes[L] = ok ? (unsigned char)S.numPlanes[S.wbeg + L] : 0;
+        R.seen[L] = 0; R.ndd[L] = 0; R.nsc[L] = 0;
+    }
+    wave_sync();
+    HS_TICK(9)
+    phase_pre(S, R);
+    HS_TICK(0)
+    // ---- compact list of the octet's existing bodies in slot-major order (a third of the box slots are empty)
+    int nbodies;
+    {
+        int base = 0;
+        for (int c = 0; c < kMaxBodyRounds; ++c) {
+            const int t = c * 64 + L;
+            const int slot = t >> 3, g = t & 7;
+            const bool on = slot < NS && R.meta[slot][g] != 0;
+            const unsigned long long m = __ballot(on);
+            if (on) R.bodies[base + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)t;
+            base += __popcll(m);
+        }
+        nbodies = base;
+    }
+    wave_sync();
+    BodyReg br[kMaxBodyRounds];
+#pragma unroll
+    for (int r = 0; r < kMaxBodyRounds; ++r) {
+        BodyReg &b = br[r];
+        b.slot = -1; b.g = 0; b.meta = 0; b.force = {0.f, 0.f, 0.f}; b.torque = 0.f; b.np = 0; b.vidx = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b.off[j] = 0.f; b.lam[j] = 0.f; }
+        if (r * 64 + L < nbodies) {
+            const int t = R.bodies[r * 64 + L];
+            b.slot = t >> 3; b.g = t & 7; b.meta = R.meta[b.slot][b.g];
+            if (b.slot >= kAgentSlot0) {
+                const int a = b.slot - kAgentSlot0, w = S.wbeg + b.g;
+                b.force = {S.aforce(0 * kMaxAgents + a, w), S.aforce(1 * kMaxAgents + a, w), S.aforce(2 * kMaxAgents + a, w)};
+                b.torque = S.aforce(3 * kMaxAgents + a, w);
+            }
+        }
+    }
+    // ---- integrate for the first substep (the later ones happen at the end of the velocity pass)
+#pragma unroll
+    for (int r = 0; r < kMaxBodyRounds; ++r) {
+        if (r * 64 >= nbodies) break;
+        BodyReg &b = br[r];
+        if (b.slot >= 0) {
+            const bool dyn = meta_resp(b.meta) == RESP_DYNAMIC;
+            const V3 lin = dyn ? rld3(R.lin, b.slot, b.g) : V3{0.f, 0.f, 0.f}, ang = dyn ? rld3(R.ang, b.slot, b.g) : V3{0.f, 0.f, 0.f};
+            integrate_body(S, R, b, rld3(R.pos, b.slot, b.g), rld4(R.rot, b.slot, b.g), lin, ang);
+        }
+    }
+    wave_sync();
+    HS_TICK(1)
+    for (int sub = 0; sub < kNumSubsteps; ++sub) {
+        const ItemCounts ic = phase_detect(S, R, NS);
+        HS_TICK(2)
+        phase_sat(S, R, ic);
+        HS_TICK(3)
+        phase_dd<true>(S, R);
+        HS_TICK(4)
+#pragma unroll
+        for (int r = 0; r < kMaxBodyRounds; ++r) {
+            if (r * 64 >= nbodies) break;
+            if (br[r].slot >= 0) body_pos_item(S, R, br[r]);
+        }
+        wave_sync();
+        HS_TICK(5)
+        phase_dd<false>(S, R);
+        HS_TICK(6)
+        if (sub + 1 < kNumSubsteps) {
+#pragma unroll
+            for (int r = 0; r < kMaxBodyRounds; ++r) {
+                if (r * 64 >= nbodies) break;
+                if (br[r].slot >= 0) body_vel_item<true>(S, R, br[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kMaxBodyRounds; ++r) {
+                if (r * 64 >= nbodies) break;
+                if (br[r].slot >= 0) body_vel_item<false>(S, R, br[r]);
+            }
+        }
+        wave_sync();
+        HS_TICK(7)
+    }
+    phase_post(S, R);
+    wave_sync();
+    // ---- LDS -> the octet's columns
+    copy_out(S.bpos, o, &R.pos[0][0][0]); copy_out(S.brot, o, &R.rot[0][0][0]);
+    copy_out(S.blin, o, &R.lin[0][0][0]); copy_out(S.bang, o, &R.ang[0][0][0]);
+    copy_out(S.bmeta, o, &R.meta[0][0]);
+    wave_sync();                          // the write-back is complete before a regenerated level overwrites it
+    HS_TICK(8)
+    // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
+    if (L < S.wcnt) reset_world(S, S.wbeg + L);
+#ifdef HS_PHASE_TIMING
+    if (L == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[(size_t)o * 10 + i] += acc[i];
+#endif
+#undef HS_TICK
+}
+
+}  // namespace hs

@@ -1,10 +1,14 @@
 // Simulator state in HBM.
 //
-// Internal entity-component columns are struct-of-arrays ACROSS WORLDS: element (field f, slot s,
-// world w) lives at base[(f*SLOTS + s)*N + w], so a wave whose lanes walk consecutive worlds (or a
-// group that loads one world's slots) issues coalesced dword loads.  This replaces Madrona's ECS
-// archetype tables: every capacity is a small compile-time bound
-// (src/sim.hpp:39-41), so slots are fixed and nothing is ever compacted or sorted.
+// Internal entity-component columns are struct-of-arrays ACROSS WORLDS, tiled by kTile = 8 consecutive worlds
+// (an "octet"): element (row r, world w) of a column with ROWS rows per world lives at
+//     base[((w / 8) * ROWS + r) * 8 + (w % 8)]          (struct Col below; r = component * SLOTS + slot)
+// so the whole working set of an octet is ONE contiguous block per column (e.g. 51 rows x 8 worlds x 4 B = 1.6 KB of
+// positions) that a wave streams with full 256-byte transactions, and inside the block the 8 worlds of a row are
+// adjacent: a wave whose lanes are (row, world) pairs reads and writes conflict-free.  The physics kernel gives
+// one wave to an octet, the observation kernel one workgroup.  This replaces Madrona's ECS archetype tables
+// (SURVEY §2 row 9): every capacity is a small compile-time bound (src/sim.hpp:39-41), so slots are fixed and
+// nothing is ever compacted or sorted.
 //
 // Exported tensors keep the reference's contract instead (AoS, row-major, agent row =
 // world*A + slot; src/mgr.cpp:1062-1331) because scripts alias them in place.
@@ -13,6 +17,15 @@
 
 namespace hs {
 
+constexpr int kTile = 8;          // worlds per octet
+// A column with ROWS rows per world, tiled by octets.  Allocated for ceil(N / 8) octets.
+template <typename T, int ROWS> struct Col {
+    T *p;
+    static constexpr int kRows = ROWS;
+    HSD T &operator()(int row, int w) const { return p[((size_t)(w >> 3) * ROWS + row) * kTile + (w & 7)]; }
+    HSD T *octet(int o) const { return p + (size_t)o * ROWS * kTile; }       // rows x 8 worlds, contiguous
+};
+
 struct SimState {
     int N;                 // worlds in this shard
     int A;                 // maxAgentsPerWorld = maxHiders + maxSeekers (src/mgr.cpp:684)
@@ -20,18 +33,18 @@ struct SimState {
     RandKey initKey;       // rand::initKey(seed) (src/mgr.cpp:678)
     int minHiders, maxHiders, minSeekers, maxSeekers;
     int worldOffset;
-    int wbeg, wcnt;        // world range owned by a workgroup of k_physics (set inside the kernel)
+    int wbeg, wcnt;        // the octet's first world and world count (set inside k_physics)
 
     // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
-    float *bpos;           // [3][17][N]
-    float *brot;           // [4][17][N]  w,x,y,z
-    float *blin;           // [3][17][N]
-    float *bang;           // [3][17][N]
-    int *bmeta;            // [17][N]     meta_pack()
-    float *aforce;         // [4][6][N]   ExternalForce xyz + ExternalTorque z of the agents
+    Col<float, 3 * kNumDSlots> bpos;       // row = component * 17 + slot
+    Col<float, 4 * kNumDSlots> brot;       // w,x,y,z
+    Col<float, 3 * kNumDSlots> blin;
+    Col<float, 3 * kNumDSlots> bang;
+    Col<int, kNumDSlots> bmeta;            // meta_pack()
+    Col<float, 4 * kMaxAgents> aforce;     // ExternalForce xyz + ExternalTorque z of the agents; row = component * 6 + agent
     // --- static geometry
-    float *walls;          // [4][36][N]  cx, cy, hx, hy
-    float *planes;         // [4][3][N]   nx, ny, nz, d
+    Col<float, 4 * kMaxWalls> walls;       // cx, cy, hx, hy; row = component * 36 + wall
+    Col<float, 4 * kMaxPlanes> planes;     // nx, ny, nz, d;  row = component * 3 + plane
     int *numWalls;         // [N]
     int *numPlanes;        // [N]
     // --- world scalars (Sim fields src/sim.hpp:326-362 and singletons :105-121)
@@ -42,10 +55,10 @@ struct SimState {
     float *hiderTeamReward;      // [N]
     int *counts;    // [N] numHiders | numSeekers<<4 | numActiveAgents<<8 | numActiveBoxes<<12 | numActiveRamps<<16 | seekersFirst<<20
     int *teams;     // [N] hiders[3] (3 bits each, bits 0-8), seekers[3] (bits 9-17), agentType[6] (bits 18-23), agentActive[6] (bits 24-29)
-    int *runningScores;          // [2][N]
+    Col<int, 2> runningScores;
     // --- grab joints, one per agent slot
-    int *grabOther;        // [6][N]  D-slot or -1
-    float *grabData;       // [kGrabWords][6][N]  r2 xyz, attach2 wxyz, separation, r1 xyz, attach1 wxyz
+    Col<int, kMaxAgents> grabOther;                   // D-slot or -1
+    Col<float, kGrabWords * kMaxAgents> grabData;     // row = word * 6 + agent: r2 xyz, attach2 wxyz, separation, r1 xyz, attach1 wxyz
 
     // --- exported columns (AoS)
     int32_t *xReset, *xPrep, *xAction, *xSelfType, *xSeed, *xDone, *xPolicy;
@@ -53,20 +66,13 @@ struct SimState {
     float *xLidar, *xReward, *xGlobalPos, *xEpisodeResult;
     int32_t *xCkptCtrl;    // [N]  CheckpointControl::trigger (sim.hpp:279-281)
     uint8_t *xCkpt;        // [N][sizeof(hs_checkpoint)]  (include/hideseek.h, sim.hpp:283-313)
-    // --- substep scratch of the physics kernel (hs_k_pipeline.h) that does not fit its LDS-resident working set,
-    // all SoA across worlds
-    int *gman;             // [2][17][N] (double-buffered by substep parity)     ground manifold: np | vertex ids << 4 | has-static-candidates << 30
-    float *goff, *glam;    // [4][17][N]  ground manifold plane offsets / accumulated multipliers
-    int *ndd, *nsc;        // [N]         candidate counts
-    int *ddPair, *scPair;  // [kMaxDDCand][N] a | b << 8 ; [kMaxSCand][N] body | static << 8
-    int *wflags;           // [N]         1 = world has a grab joint
-    void *wsDD, *wsSC;     // contact-manifold workspace: [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS
-    int *bodyList;         // [N][17] existing bodies of a workgroup's worlds, compacted once per step (local world << 5 | slot)
-    int *satList, *wallList, *ddwList;   // work lists of one substep; workgroup b of k_physics uses the slice of its worlds
+    // --- contact-manifold workspace of the physics kernel (hs_k_physics.h): written by the lane that ran the convex
+    // test, read by the lanes that solve the contact; [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS (L2-resident)
+    void *wsDD, *wsSC;
     int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, -, -
                            // (include/hideseek.h hs_device_status); bumped only when something happens
     int *hostFlag;         // pinned host word (device-visible): set to 1 together with any change of status
-    long long *phaseTicks; // [workgroups][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
+    long long *phaseTicks; // [octets][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
 };
 
 HSD int cnt_hiders(int c) { return c & 15; }

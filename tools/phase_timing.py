@@ -16,14 +16,14 @@ steps = 240
 for i in range(steps):
     act[:, :2] = torch.randint(-5, 5, (N * 4, 2), dtype=torch.int32, device="cuda")
     sim.step()
-nb = (N + 31) // 32
+nb = (N + 7) // 8          # one wave (workgroup) per octet of 8 worlds
 out = np.zeros((nb, 10), np.int64)
 L = sim._L
 L.hs_debug_phase_ticks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 n = L.hs_debug_phase_ticks(sim._h, out.ctypes.data, nb)
 us = out[:n] / 100.0 / steps     # 100 MHz ticks -> us per step
 names = ["pre", "integrate", "detect", "sat", "dd_pos", "body_pos", "dd_vel", "body_vel", "post+store", "load"]
-print("phase      mean_us  min_us  max_us   (per step, over %d workgroups)" % n)
+print("phase      mean_us  min_us  max_us   (per step, over %d waves = octets)" % n)
 for i, nm in enumerate(names):
     print(f"{nm:10s} {us[:, i].mean():7.1f} {us[:, i].min():7.1f} {us[:, i].max():7.1f}")
 tot = us.sum(axis=1)
