@@ -87,8 +87,11 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     const hs::SimState &S = s->S;
     const int N = S.N;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
-    if (!first && (stages & 1))
-        hipLaunchKernelGGL(hs::k_physics, dim3((N + hs::kTile - 1) / hs::kTile), dim3(hs::kPhysThreads), 0, strm, S);
+    if (!first && (stages & 1)) {
+        // 17 body slots x 8 worlds need a third round of 64 lanes only with 6 agents per world
+        if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3((N + hs::kTile - 1) / hs::kTile), dim3(hs::kPhysThreads), 0, strm, S);
+        else hipLaunchKernelGGL(hs::k_physics<2>, dim3((N + hs::kTile - 1) / hs::kTile), dim3(hs::kPhysThreads), 0, strm, S);
+    }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
     if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world

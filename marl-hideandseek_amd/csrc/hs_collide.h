@@ -120,6 +120,29 @@ HSD HullRef hull_ref_body(int obj, V3 pos, Q rot) {
     h.e = obj == OBJ_RAMP ? V3{1.f, 1.f, 1.f} : obj_half_extents(obj);
     return h;
 }
+// What a hull is built from: 11 words instead of HullRef's 16.  The convex test keeps the sources of its two hulls
+// and builds the HullRefs it needs per stage (face normals: the lane's own X / Y assignment; edge directions and
+// clipping: A / B), so that only one pair of HullRefs is live at a time.
+struct HullSrc { int kind; V3 c; Q q; V3 e; };
+HSD HullSrc hull_src_body(int obj, V3 pos, Q rot) {
+    return {obj == OBJ_RAMP ? HULL_WEDGE : HULL_BOX, pos, rot, obj == OBJ_RAMP ? V3{1.f, 1.f, 1.f} : obj_half_extents(obj)};
+}
+// the identity rotation gives exactly hull_ref_wall's axes (m3_from_quat of {1,0,0,0} is the unit matrix)
+HSD HullSrc hull_src_wall(float cx, float cy, float hx, float hy) {
+    return {HULL_BOX, V3{cx, cy, 1.25f}, Q{1.f, 0.f, 0.f, 0.f}, V3{hx, hy, 1.25f}};
+}
+HSD HullSrc hull_src_sel(bool c, const HullSrc &a, const HullSrc &b) {
+    HullSrc r;
+    r.kind = c ? a.kind : b.kind; r.c = vsel(c, a.c, b.c); r.e = vsel(c, a.e, b.e);
+    r.q = {c ? a.q.w : b.q.w, c ? a.q.x : b.q.x, c ? a.q.y : b.q.y, c ? a.q.z : b.q.z};
+    return r;
+}
+HSD HullRef hull_from(const HullSrc &s) {
+    M3 m = m3_from_quat(s.q);
+    HullRef h;
+    h.kind = s.kind; h.c = s.c; h.ax = m.c0; h.ay = m.c1; h.az = m.c2; h.e = s.e;
+    return h;
+}
 HSD HullRef hull_ref_wall(float cx, float cy, float hx, float hy) {
     HullRef h;
     h.kind = HULL_BOX;
@@ -349,23 +372,14 @@ HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, con
 // the second half; they exchange results with cross-lane shuffles and combine them exactly as the sequential
 // loop would (strictly-greater updates, earlier axis wins ties).  Contact generation then runs on the low
 // lane only (it owns the LDS clip scratch); the partner returns false.
-HSD HullRef hull_sel(bool c, const HullRef &a, const HullRef &b) {
-    HullRef r;
-    r.kind = c ? a.kind : b.kind; r.c = vsel(c, a.c, b.c); r.ax = vsel(c, a.ax, b.ax); r.ay = vsel(c, a.ay, b.ay);
-    r.az = vsel(c, a.az, b.az); r.e = vsel(c, a.e, b.e);
-    return r;
-}
-HSD bool collide_hulls(const HullRef &A, const HullRef &B, const ClipBuf &cb, RawManifold &m, const bool hi) {
-    WedgeVerts wa = {}, wb = {};
-    if (A.kind == HULL_WEDGE) wedge_verts(A, wa);
-    if (B.kind == HULL_WEDGE) wedge_verts(B, wb);
-    // ---- face normals: this lane takes the faces of X against the vertices of Y
+HSD bool collide_hulls(const HullSrc &sa, const HullSrc &sb, const ClipBuf &cb, RawManifold &m, const bool hi) {
+    // ---- face normals: this lane takes the faces of X against the vertices of Y (X = A on the low lane, B on its partner)
     float bestA, bestB; int fa, fb;
     {
-        const HullRef X = hull_sel(hi, B, A), Y = hull_sel(hi, A, B);
-        WedgeVerts wx, wy;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { wx.v[i] = vsel(hi, wb.v[i], wa.v[i]); wy.v[i] = vsel(hi, wa.v[i], wb.v[i]); }
+        const HullRef X = hull_from(hull_src_sel(hi, sb, sa)), Y = hull_from(hull_src_sel(hi, sa, sb));
+        WedgeVerts wx = {}, wy = {};
+        if (X.kind == HULL_WEDGE) wedge_verts(X, wx);
+        if (Y.kind == HULL_WEDGE) wedge_verts(Y, wy);
         float best = 0.f; int fx = -1; int sep = 0;
         const int xnf = hull_nf(X);
         for (int f = 0; f < xnf; ++f) {
@@ -379,6 +393,10 @@ HSD bool collide_hulls(const HullRef &A, const HullRef &B, const ClipBuf &cb, Ra
         bestA = hi ? best_o : best; fa = hi ? fx_o : fx;
         bestB = hi ? best : best_o; fb = hi ? fx : fx_o;
     }
+    const HullRef A = hull_from(sa), B = hull_from(sb);
+    WedgeVerts wa = {}, wb = {};
+    if (A.kind == HULL_WEDGE) wedge_verts(A, wa);
+    if (B.kind == HULL_WEDGE) wedge_verts(B, wb);
     // ---- edge-direction crosses: pairs p = i * bned + j, first half on the low lane
     float bestE = 0.f; int ea = -1, eb = -1; V3 axE = {0.f, 0.f, 0.f};
     {

@@ -31,8 +31,10 @@ namespace hs {
 
 constexpr int kPhysThreads = 64;                   // one wave
 constexpr int kPhysWorlds = kTile;                 // worlds per workgroup
-constexpr int kMaxBodyRounds = (kNumDSlots * kTile + 63) / 64;     // 3 (17 slots x 8 worlds = 136 bodies at most)
 constexpr int kMaxItems = kTile * (kMaxDDCand + kMaxSCand);        // convex-test items of an octet
+constexpr int kLdsWalls = 32;                      // walls per world staged in LDS for the broadphase (a world has
+                                                   // 4..34; the rare ones beyond 32 are read from global memory)
+static_assert(kMaxSCand <= 32 && kMaxDDCand <= 16, "accepted-manifold masks are one word per world");
 
 // ---- the octet's resident working set (LDS) ----
 // Every column is [row][world of the octet] exactly like its block in HBM (hs_state.h Col), so loading and storing
@@ -51,7 +53,7 @@ struct alignas(16) OctRes {
     union {
         struct {
             float lo[3][kNumDSlots][kTile], hi[3][kNumDSlots][kTile];   // hull AABBs: integrate -> detect
-            float wall[4][kMaxWalls][kTile];                            // cx, cy, hx, hy: staged by detect
+            float wall[4][kLdsWalls][kTile];                            // cx, cy, hx, hy: staged by detect
         } det;
         struct {
             float clip[kClipWords];                                     // polygon clipping of the convex tests
@@ -61,7 +63,11 @@ struct alignas(16) OctRes {
     unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 8
     unsigned short scPair[kMaxSCand][kTile];    // body | static << 8  (static = wall index, 36 + plane index)
     unsigned short scInfo[kNumDSlots][kTile];   // per body: first static candidate | count << 8
+    unsigned int scAcc[kTile];                  // bit k: static candidate k of the world has a manifold (set by the convex test)
+    unsigned int ddAcc[kTile];                  // bit k: body-body candidate k has a manifold
+    float plane0[4][kTile];                     // the ground plane nx, ny, nz, d of every world
     unsigned char bodies[kNumDSlots * kTile];   // compact list of existing bodies: slot << 3 | world
+    unsigned char wallBodies[kNumDSlots * kTile];   // bodies with a wall / extra-plane manifold in this substep
     unsigned char actGL[kMaxAgents][kTile];     // grab / lock requests
     unsigned char numWalls[kTile], numPlanes[kTile], ndd[kTile], nsc[kTile], seen[kTile], hasGrab[kTile];
 };
@@ -95,9 +101,11 @@ HSD void derive_velocity(BodyS &b) {
     b.ang = dq.w >= 0.f ? wv : -wv;
 }
 
-// Everything of the LDS that one phase wrote is read by other lanes in the next: one wave, so program order is
-// enough for the hardware (LDS operations of a wave execute in order) — this keeps the compiler from moving them.
-HSD void wave_sync() { __syncthreads(); }
+// Hand-offs between the lanes of the wave.  Through LDS: the LDS operations of a wave execute in order, so all it
+// takes is that the compiler keeps them in program order and the data has landed (lgkmcnt).  Through global memory
+// (the manifold workspace, the agents' forces): the stores must have left the wave first (vmcnt).
+HSD void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+HSD void mem_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // Geometry view of one world of the octet for trace_ray (hs_rays.h): bodies from the resident columns, walls and
 // the (at most 3) planes from global memory (the rays of the physics kernel — lock / grab, seeker -> hider line
@@ -116,8 +124,6 @@ struct ResGeom {
 // What a body's lane keeps in registers for the whole step: which body it is, the agent's force / torque, and the
 // ground-plane manifold of the current substep (up to 4 deepest vertices, hs_collide.h ground_manifold).
 struct BodyReg {
-    int slot, g;             // -1: no body in this (round, lane)
-    int meta;
     V3 force; float torque;  // ExternalForce / ExternalTorque.z (agents)
     int np, vidx;            // ground manifold: contact count, 3 bits of vertex index per contact
     float off[4], lam[4];    // plane offsets, accumulated normal multipliers
@@ -138,12 +144,14 @@ HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
 
 // ------------------------------------------------------------------------------------------
 // Start of a substep for one body: remember the pose, semi-implicit Euler step (gravity, agent force and
-// torque, gyroscopic term), refresh the hull AABB and the ground-plane manifold.
-HSD void integrate_body(const SimState &S, OctRes &R, BodyReg &b, V3 pos, Q rot, V3 lin, V3 ang) {
-    const int slot = b.slot, g = b.g, meta = b.meta;
+// torque, gyroscopic term), refresh the hull AABB and the ground-plane manifold (registers of the body's lane).
+HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta) {
     const int obj = meta_obj(meta);
+    const bool dyn = meta_resp(meta) == RESP_DYNAMIC;
+    V3 pos = rld3(R.pos, slot, g); Q rot = rld4(R.rot, slot, g);
     rst3(R.ppos, slot, g, pos); rst4(R.prot, slot, g, rot);
-    if (meta_resp(meta) == RESP_DYNAMIC) {
+    if (dyn) {
+        V3 lin = rld3(R.lin, slot, g), ang = rld3(R.ang, slot, g);
         const float h = kSubstepH;
         const float invM = obj_inv_mass(obj);
         const V3 invI = obj_inv_inertia(obj);
@@ -167,10 +175,9 @@ HSD void integrate_body(const SimState &S, OctRes &R, BodyReg &b, V3 pos, Q rot,
     b.np = 0; b.vidx = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) b.lam[j] = 0.f;
-    if (meta_resp(meta) == RESP_DYNAMIC && R.numPlanes[g] >= 1) {
-        const int w = S.wbeg + g;
-        const V3 pn = {S.planes(0 * kMaxPlanes, w), S.planes(1 * kMaxPlanes, w), S.planes(2 * kMaxPlanes, w)};
-        b.np = ground_manifold(hb, pn, S.planes(3 * kMaxPlanes, w), &b.vidx, b.off);
+    if (dyn && R.numPlanes[g] >= 1) {
+        const V3 pn = {R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
+        b.np = ground_manifold(hb, pn, R.plane0[3][g], &b.vidx, b.off);
     }
 }
 
@@ -184,12 +191,12 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
     constexpr int G = 8, JB = (kNumDSlots + G - 1) / G;
     const int L = threadIdx.x, g = L / G, l = L % G;
     const int o = blockIdx.x;
-    // the octet's walls -> LDS (one contiguous block; rows beyond a world's count are never read)
-    {
-        const float4 *src = (const float4 *)S.walls.octet(o);
-        float4 *dst = (float4 *)&R.u.det.wall[0][0][0];
-        for (int i = L; i < 4 * kMaxWalls * kTile / 4; i += 64) dst[i] = src[i];
+    // the octet's walls -> LDS (rows beyond a world's count are never read)
+    for (int i = L; i < 4 * kLdsWalls * kTile; i += 64) {
+        const int c = i / (kLdsWalls * kTile), r = i - c * (kLdsWalls * kTile);       // r = wall * 8 + world
+        (&R.u.det.wall[0][0][0])[i] = S.walls.octet(o)[c * (kMaxWalls * kTile) + r];
     }
+    if (l == 0) { R.scAcc[g] = 0u; R.ddAcc[g] = 0u; }
     wave_sync();
     const int nwl = R.numWalls[g], npl = R.numPlanes[g];
     int tot_items = 0;
@@ -206,6 +213,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         if (have[jb]) { lo[jb] = rld3(R.u.det.lo, slot, g); hi[jb] = rld3(R.u.det.hi, slot, g); }
     }
     // The loops run over the OTHER body / the wall, each read from LDS once and tested against all of the lane's slots.
+#pragma unroll 4
     for (int j = 1; j < NS; ++j) {
         const int mj = R.meta[j][g];
         if (mj == 0) continue;
@@ -218,8 +226,14 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
                 lo[jb].z <= hij.z && loj.z <= hi[jb].z) dd_mask[jb] |= 1u << j;
         }
     }
+#pragma unroll 4
     for (int k = 0; k < nwl; ++k) {
-        const float cx = R.u.det.wall[0][k][g], cy = R.u.det.wall[1][k][g], hx = R.u.det.wall[2][k][g], hy = R.u.det.wall[3][k][g];
+        float cx, cy, hx, hy;
+        if (k < kLdsWalls) { cx = R.u.det.wall[0][k][g]; cy = R.u.det.wall[1][k][g]; hx = R.u.det.wall[2][k][g]; hy = R.u.det.wall[3][k][g]; }
+        else {
+            const int w = S.wbeg + g;
+            cx = S.walls(0 * kMaxWalls + k, w); cy = S.walls(1 * kMaxWalls + k, w); hx = S.walls(2 * kMaxWalls + k, w); hy = S.walls(3 * kMaxWalls + k, w);
+        }
         const float wx0 = cx - hx, wx1 = cx + hx, wy0 = cy - hy, wy1 = cy + hy;
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
@@ -326,13 +340,11 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         const int oa = meta_obj(R.meta[a][g]);
         const V3 pa = rld3(R.pos, a, g);
         const Q qa = rld4(R.rot, a, g);
-        const HullRef ha = hull_ref_body(oa, pa, qa);
         RawManifold raw;
-        if (!hi) { if (isdd) wsDD[kk].np = 0; else wsSC[kk].np = 0; }
         if (!isdd && bsel >= kMaxWalls) {
             const int p = bsel - kMaxWalls;
             const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
-            if (!hi && collide_hull_plane(ha, pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
+            if (!hi && collide_hull_plane(hull_ref_body(oa, pa, qa), pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
                 ManS m;
                 m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
                 m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
@@ -344,20 +356,21 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                     m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                 }
                 wsSC[kk] = m;
+                atomicOr(&R.scAcc[g], 1u << kk);
             }
             continue;
         }
         int ob; V3 pb = {0.f, 0.f, 0.f}; Q qb = {1.f, 0.f, 0.f, 0.f};
-        HullRef hb;
+        HullSrc hb;
         if (isdd) {
             ob = meta_obj(R.meta[bsel][g]); pb = rld3(R.pos, bsel, g); qb = rld4(R.rot, bsel, g);
-            hb = hull_ref_body(ob, pb, qb);
+            hb = hull_src_body(ob, pb, qb);
         } else {
             ob = OBJ_WALL;      // (the staged walls share their LDS with the clip buffers: from global memory here)
-            hb = hull_ref_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
+            hb = hull_src_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
                                S.walls(2 * kMaxWalls + bsel, w), S.walls(3 * kMaxWalls + bsel, w));
         }
-        if (!collide_hulls(ha, hb, cb, raw, hi)) continue;
+        if (!collide_hulls(hull_src_body(oa, pa, qa), hb, cb, raw, hi)) continue;
         const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
         const Q qai = qinv(qa);
         if (isdd) {
@@ -373,6 +386,7 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                 m.lam[j] = 0.f;
             }
             wsDD[kk] = m;
+            atomicOr(&R.ddAcc[g], 1u << kk);
         } else {
             ManS m;
             m.np = raw.np; m.muS = muS; m.muD = muD; m.pad[0] = 0.f; m.pad[1] = 0.f;
@@ -384,9 +398,10 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                 m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
             }
             wsSC[kk] = m;
+            atomicOr(&R.scAcc[g], 1u << kk);
         }
     }
-    wave_sync();          // the manifolds (global memory) are complete for the lanes that solve them
+    mem_sync();           // the manifolds (global memory) are complete for the lanes that solve them
 }
 
 // Fixed grab joint on two loaded bodies (sim.cpp:343-356): angular alignment, then anchor coincidence.
@@ -438,7 +453,7 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
     const int w = S.wbeg + g;
     const int ndd = R.ndd[g];
     const bool grab = R.hasGrab[g] != 0;
-    if (__ballot(ndd > 0 || (POS && grab)) == 0ull) return;        // nothing to do in the whole octet
+    if (__ballot(R.ddAcc[g] != 0u || (POS && grab)) == 0ull) return;        // nothing to do in the whole octet
     if (POS && grab && q == 0) {
         const int teams = S.teams[w];
         for (int a = 0; a < kMaxAgents; ++a) {
@@ -458,9 +473,10 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
     wave_sync();
     ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
     // keys of the accepted candidates, kMaxDDCand = 16: lane q inspects candidates q and q+8
+    const unsigned acc = R.ddAcc[g];
     int key0 = 0x7fffffff, key1 = 0x7fffffff;
-    if (q < ndd && wsDD[q].np > 0) { const int p = R.ddPair[q][g]; key0 = ((p & 0xff) << 8) | (p >> 8); }
-    if (q + GL < ndd && wsDD[q + GL].np > 0) { const int p = R.ddPair[q + GL][g]; key1 = ((p & 0xff) << 8) | (p >> 8); }
+    if (q < ndd && ((acc >> q) & 1u)) { const int p = R.ddPair[q][g]; key0 = ((p & 0xff) << 8) | (p >> 8); }
+    if (q + GL < ndd && ((acc >> (q + GL)) & 1u)) { const int p = R.ddPair[q + GL][g]; key1 = ((p & 0xff) << 8) | (p >> 8); }
     // rank of every accepted candidate in sorted key order (keys are unique: distinct pairs)
     int rank0 = 0, rank1 = 0, nacc = 0;
 #pragma unroll
@@ -518,85 +534,93 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Static contacts of one body, in the oracle's order: ground manifold (registers), then the body's other static
-// candidates (extra planes, walls by index); then the velocities of the substep from the pose change.
-HSD void body_pos_item(const SimState &S, OctRes &R, BodyReg &b) {
-    const int slot = b.slot, g = b.g, meta = b.meta;
-    if (meta_resp(meta) != RESP_DYNAMIC) return;
-    const int w = S.wbeg + g;
-    const int obj = meta_obj(meta);
-    const int sci = R.scInfo[slot][g];
-    BodyS me, none;
-    rbody_load(R, g, slot, me);
-    if (b.np > 0) {
-        const V3 gn = -V3{S.planes(0 * kMaxPlanes, w), S.planes(1 * kMaxPlanes, w), S.planes(2 * kMaxPlanes, w)};
-        const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+// Static contacts, in the oracle's order per body: ground manifold, then the body's other static candidates (extra
+// planes, walls by index), then the velocities of the substep from the pose change.  The ground manifold of every
+// body is solved by the body's own lane (registers).  The few bodies that also touch a wall would make their whole
+// round wait, so their wall manifolds are solved in a round of their own — one lane per such body, compacted over
+// the octet (wallBodies) — between the ground pass and the velocity derivation.
+template <int ROUNDS>
+HSD int list_wall_bodies(OctRes &R, int nbodies) {
+    const int L = threadIdx.x;
+    int n = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < b.np) b.lam[j] += solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7),
-                                                                  V3{0.f, 0.f, 0.f}, b.off[j], gmuS);
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool valid = r * 64 + L < nbodies;
+        const int t = valid ? R.bodies[r * 64 + L] : 0;
+        const int sci = valid ? R.scInfo[t >> 3][t & 7] : 0;
+        const bool on = sci != 0 && ((R.scAcc[t & 7] >> (sci & 0xff)) & ((1u << (sci >> 8)) - 1u)) != 0u;
+        const unsigned long long m = __ballot(on);
+        if (on) R.wallBodies[n + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)t;
+        n += __popcll(m);
     }
-    if (sci != 0) {
-        ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
-        const int bsc = sci & 0xff, asc = sci >> 8;
-#pragma unroll 1
-        for (int k = bsc; k < bsc + asc; ++k) {       // the body's candidates, already in solve order
-            ManS m = wsSC[k];
-            if (m.np <= 0) continue;
-            body_refresh_inertia(me);
-            const V3 n = ld3(m.n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < m.np) wsSC[k].lam[j] = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
-        }
-    }
-    if (b.np > 0 || sci != 0) rbody_store_pose(R, g, slot, me);
-    derive_velocity(me);
-    rbody_store_vel(R, g, slot, me);
+    wave_sync();
+    return n;
 }
 
-// Velocity pass over a body's static contacts; with NEXT, also the start of the following substep for the body,
-// integrated from registers.
-template <bool NEXT>
-HSD void body_vel_item(const SimState &S, OctRes &R, BodyReg &b) {
-    const int slot = b.slot, g = b.g, meta = b.meta;
-    if (meta_resp(meta) != RESP_DYNAMIC) {
-        if (NEXT) integrate_body(S, R, b, rld3(R.pos, slot, g), rld4(R.rot, slot, g), V3{0.f, 0.f, 0.f}, V3{0.f, 0.f, 0.f});
-        return;
-    }
-    const int w = S.wbeg + g;
-    const int sci = R.scInfo[slot][g];
-    if (b.np == 0 && sci == 0) {
-        if (NEXT) integrate_body(S, R, b, rld3(R.pos, slot, g), rld4(R.rot, slot, g), rld3(R.lin, slot, g), rld3(R.ang, slot, g));
-        return;
-    }
+HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
+    if (meta_resp(meta) != RESP_DYNAMIC || b.np == 0) return;
     const int obj = meta_obj(meta);
     BodyS me, none;
     rbody_load(R, g, slot, me);
-    if (b.np > 0) {
-        const V3 gn = -V3{S.planes(0 * kMaxPlanes, w), S.planes(1 * kMaxPlanes, w), S.planes(2 * kMaxPlanes, w)};
-        const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+    const V3 gn = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
+    const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < b.np) solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7), V3{0.f, 0.f, 0.f},
-                                                      b.lam[j], gmuD);
-    }
-    if (sci != 0) {
-        const ManS *const wsSC = (const ManS *)S.wsSC + (size_t)w * kMaxSCand;
+    for (int j = 0; j < 4; ++j)
+        if (j < b.np) b.lam[j] += solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7),
+                                                              V3{0.f, 0.f, 0.f}, b.off[j], gmuS);
+    rbody_store_pose(R, g, slot, me);
+}
+HSD void ground_vel(OctRes &R, const BodyReg &b, int slot, int g, int meta) {
+    if (meta_resp(meta) != RESP_DYNAMIC || b.np == 0) return;
+    const int obj = meta_obj(meta);
+    BodyS me, none;
+    rbody_load(R, g, slot, me);
+    const V3 gn = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
+    const float gmuD = 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < b.np) solve_point_velocity<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7), V3{0.f, 0.f, 0.f},
+                                                  b.lam[j], gmuD);
+    rbody_store_vel(R, g, slot, me);
+}
+// The wall / extra-plane manifolds of the listed bodies, one lane per body, candidates in solve order.
+template <bool POS>
+HSD void wall_round(const SimState &S, OctRes &R, int nwb) {
+    for (int i = threadIdx.x; i < nwb; i += 64) {
+        const int t = R.wallBodies[i];
+        const int slot = t >> 3, g = t & 7;
+        const int sci = R.scInfo[slot][g];
         const int bsc = sci & 0xff, asc = sci >> 8;
+        const unsigned acc = R.scAcc[g];
+        ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kMaxSCand;
+        BodyS me, none;
+        rbody_load(R, g, slot, me);
 #pragma unroll 1
         for (int k = bsc; k < bsc + asc; ++k) {
+            if (!((acc >> k) & 1u)) continue;
             const ManS m = wsSC[k];
-            if (m.np <= 0) continue;
             body_refresh_inertia(me);
             const V3 n = ld3(m.n);
+            if (POS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
+                for (int j = 0; j < 4; ++j)
+                    if (j < m.np) wsSC[k].lam[j] = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < m.np) solve_point_velocity<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.lam[j], m.muD);
+            }
         }
+        if (POS) rbody_store_pose(R, g, slot, me); else rbody_store_vel(R, g, slot, me);
     }
-    if (NEXT) integrate_body(S, R, b, me.pos, me.rot, me.lin, me.ang);
-    else rbody_store_vel(R, g, slot, me);
+}
+HSD void derive_body_velocity(OctRes &R, int slot, int g, int meta) {
+    if (meta_resp(meta) != RESP_DYNAMIC) return;
+    BodyS me;
+    me.pos = rld3(R.pos, slot, g); me.rot = rld4(R.rot, slot, g);
+    me.ppos = rld3(R.ppos, slot, g); me.prot = rld4(R.prot, slot, g);
+    derive_velocity(me);
+    rbody_store_vel(R, g, slot, me);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -777,8 +801,10 @@ HSD void phase_post(const SimState &S, OctRes &R) {
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
-    __shared__ OctRes R;
+// ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
+// 6 agents (17 slots x 8 worlds = 136 bodies at most).
+template <int ROUNDS>
+HSD void physics_step(SimState &S, OctRes &R) {
     const int L = threadIdx.x, o = blockIdx.x;
     S.wbeg = o * kTile;
     S.wcnt = min(kTile, S.N - S.wbeg);
@@ -800,6 +826,7 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
         R.numPlanes[L] = ok ? (unsigned char)S.numPlanes[S.wbeg + L] : 0;
         R.seen[L] = 0; R.ndd[L] = 0; R.nsc[L] = 0;
     }
+    if (L < 4 * kTile) (&R.plane0[0][0])[L] = S.planes((L >> 3) * kMaxPlanes, S.wbeg + (L & 7));
     wave_sync();
     HS_TICK(9)
     phase_pre(S, R);
@@ -808,7 +835,8 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     int nbodies;
     {
         int base = 0;
-        for (int c = 0; c < kMaxBodyRounds; ++c) {
+#pragma unroll
+        for (int c = 0; c < ROUNDS; ++c) {
             const int t = c * 64 + L;
             const int slot = t >> 3, g = t & 7;
             const bool on = slot < NS && R.meta[slot][g] != 0;
@@ -819,36 +847,29 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
         nbodies = base;
     }
     wave_sync();
-    BodyReg br[kMaxBodyRounds];
+    // A body keeps its (round, lane) for the whole step: which body it is comes from the list, its ground manifold
+    // and the agent's force stay in registers.
+#define HS_BODY(r) const bool valid = (r) * 64 + L < nbodies; const int t_ = valid ? R.bodies[(r) * 64 + L] : 0; \
+                   const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
+    BodyReg br[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < kMaxBodyRounds; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         BodyReg &b = br[r];
-        b.slot = -1; b.g = 0; b.meta = 0; b.force = {0.f, 0.f, 0.f}; b.torque = 0.f; b.np = 0; b.vidx = 0;
+        b.force = {0.f, 0.f, 0.f}; b.torque = 0.f; b.np = 0; b.vidx = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { b.off[j] = 0.f; b.lam[j] = 0.f; }
-        if (r * 64 + L < nbodies) {
-            const int t = R.bodies[r * 64 + L];
-            b.slot = t >> 3; b.g = t & 7; b.meta = R.meta[b.slot][b.g];
-            if (b.slot >= kAgentSlot0) {
-                const int a = b.slot - kAgentSlot0, w = S.wbeg + b.g;
-                b.force = {S.aforce(0 * kMaxAgents + a, w), S.aforce(1 * kMaxAgents + a, w), S.aforce(2 * kMaxAgents + a, w)};
-                b.torque = S.aforce(3 * kMaxAgents + a, w);
-            }
+        HS_BODY(r)
+        if (valid && slot >= kAgentSlot0) {
+            const int a = slot - kAgentSlot0, w = S.wbeg + g;
+            b.force = {S.aforce(0 * kMaxAgents + a, w), S.aforce(1 * kMaxAgents + a, w), S.aforce(2 * kMaxAgents + a, w)};
+            b.torque = S.aforce(3 * kMaxAgents + a, w);
         }
-    }
-    // ---- integrate for the first substep (the later ones happen at the end of the velocity pass)
-#pragma unroll
-    for (int r = 0; r < kMaxBodyRounds; ++r) {
-        if (r * 64 >= nbodies) break;
-        BodyReg &b = br[r];
-        if (b.slot >= 0) {
-            const bool dyn = meta_resp(b.meta) == RESP_DYNAMIC;
-            const V3 lin = dyn ? rld3(R.lin, b.slot, b.g) : V3{0.f, 0.f, 0.f}, ang = dyn ? rld3(R.ang, b.slot, b.g) : V3{0.f, 0.f, 0.f};
-            integrate_body(S, R, b, rld3(R.pos, b.slot, b.g), rld4(R.rot, b.slot, b.g), lin, ang);
-        }
+        // integrate for the first substep (the later ones happen at the end of the velocity pass)
+        if (valid) integrate_body(R, b, slot, g, meta);
     }
     wave_sync();
     HS_TICK(1)
+#pragma unroll 1
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect(S, R, NS);
         HS_TICK(2)
@@ -856,38 +877,36 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
         HS_TICK(3)
         phase_dd<true>(S, R);
         HS_TICK(4)
+        const int nwb = list_wall_bodies<ROUNDS>(R, nbodies);
 #pragma unroll
-        for (int r = 0; r < kMaxBodyRounds; ++r) {
-            if (r * 64 >= nbodies) break;
-            if (br[r].slot >= 0) body_pos_item(S, R, br[r]);
-        }
+        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) ground_pos(R, br[r], slot, g, meta); }
         wave_sync();
+        if (nwb > 0) { wall_round<true>(S, R, nwb); wave_sync(); }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
+        mem_sync();                       // (also: the wall manifolds' multipliers for the velocity pass)
         HS_TICK(5)
         phase_dd<false>(S, R);
         HS_TICK(6)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) ground_vel(R, br[r], slot, g, meta); }
+        wave_sync();
+        if (nwb > 0) { wall_round<false>(S, R, nwb); wave_sync(); }
         if (sub + 1 < kNumSubsteps) {
 #pragma unroll
-            for (int r = 0; r < kMaxBodyRounds; ++r) {
-                if (r * 64 >= nbodies) break;
-                if (br[r].slot >= 0) body_vel_item<true>(S, R, br[r]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < kMaxBodyRounds; ++r) {
-                if (r * 64 >= nbodies) break;
-                if (br[r].slot >= 0) body_vel_item<false>(S, R, br[r]);
-            }
+            for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) integrate_body(R, br[r], slot, g, meta); }
+            wave_sync();
         }
-        wave_sync();
         HS_TICK(7)
     }
+#undef HS_BODY
     phase_post(S, R);
     wave_sync();
     // ---- LDS -> the octet's columns
     copy_out(S.bpos, o, &R.pos[0][0][0]); copy_out(S.brot, o, &R.rot[0][0][0]);
     copy_out(S.blin, o, &R.lin[0][0][0]); copy_out(S.bang, o, &R.ang[0][0][0]);
     copy_out(S.bmeta, o, &R.meta[0][0]);
-    wave_sync();                          // the write-back is complete before a regenerated level overwrites it
+    mem_sync();                           // the write-back is complete before a regenerated level overwrites it
     HS_TICK(8)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
     if (L < S.wcnt) reset_world(S, S.wbeg + L);
@@ -895,6 +914,12 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     if (L == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[(size_t)o * 10 + i] += acc[i];
 #endif
 #undef HS_TICK
+}
+
+template <int ROUNDS>
+__global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
+    __shared__ OctRes R;
+    physics_step<ROUNDS>(S, R);
 }
 
 }  // namespace hs
