@@ -71,7 +71,8 @@ void set_desc(hs_sim *s, int id, void *ptr, int dtype, std::initializer_list<int
 void launch_observe(hs_sim *s, hipStream_t strm) {
     const hs::SimState &S = s->S;
     if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
-    const int N = S.N;
+    // one workgroup per world; the grid covers whole groups of 8 octets (k_observe's block -> world mapping)
+    const int N = ((S.N + hs::kTile - 1) / hs::kTile + 7) / 8 * 64;
     const int nt = (s->A * hs::kRaysPerAgent + 63) / 64 * 64;      // one lane per ray, whole waves
     if (nt <= 64) hipLaunchKernelGGL(hs::k_observe<64>, dim3(N), dim3(64), 0, strm, S);
     else if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);

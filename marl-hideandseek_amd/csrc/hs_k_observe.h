@@ -1,8 +1,11 @@
 // Observation kernel: collectObservationsSystem (src/sim.cpp:448-565), computeVisibilitySystem CPU
 // branch (:567-605,663-708), lidarSystem (:712-759), globalPositionsDebugSystem (:895-941).
 //
-// One 256-thread workgroup per world; the world's poses, velocities and static geometry are
-// staged once into LDS (coalesced dword loads from the world-fastest SoA columns).
+// One workgroup per world (a lane per ray); the world's poses, velocities and static geometry are staged once
+// into LDS.  The 8 workgroups of an octet (hs_state.h) read the same contiguous blocks of the tiled columns, so
+// the block index is mapped to the world such that they land on the same XCD (workgroups are dealt round-robin
+// over the 8 XCDs, each with its own L2) and next to each other in time: the octet's blocks come from HBM once.
+// The observation rows of the world's agents are assembled in LDS and leave as whole contiguous rows.
 //
 // Rays (A*30 lidar + A*16 visibility) are cast in two passes so that the expensive, divergent part
 // runs on full waves:
@@ -22,6 +25,8 @@ namespace hs {
 constexpr int kRaysPerAgent = 46;                          // 30 lidar + 16 visibility targets
 constexpr int kMaxRays = kMaxAgents * kRaysPerAgent;       // 276
 constexpr int kMaxPairs = 1536;
+constexpr int kObsSelf = 0, kObsAgents = 13, kObsBoxes = kObsAgents + (kMaxAgents - 1) * 14, kObsRamps = kObsBoxes + kMaxBoxes * 17;
+constexpr int kObsRowFloats = kObsRamps + kMaxRamps * 14;   // 264
 
 struct ObsShared {
     WorldGeom g;
@@ -33,6 +38,9 @@ struct ObsShared {
     unsigned short pairs[kMaxPairs];                       // ray << 5 | body slot
     int nPairs;
     float lidarSin[30], lidarCos[30];                      // hs_sincosf of the 30 lidar angles, once per workgroup
+    // the world's observation rows, assembled here and copied out as contiguous rows:
+    // per agent self 13 | other agents 5 x 14 | boxes 9 x 17 | ramps 2 x 14 (sim.hpp:171-215)
+    float rows[kMaxAgents][kObsRowFloats];
 };
 
 HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
@@ -77,7 +85,10 @@ template <int NT>
 __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     __shared__ ObsShared sh;
     const int tid = threadIdx.x;
-    const int w = blockIdx.x;
+    // blocks b, b + 8, ..., b + 56 (same XCD under round-robin placement) take the 8 worlds of one octet
+    const int blk = blockIdx.x;
+    const int w = (((blk >> 6) << 3) + (blk & 7)) * kTile + ((blk >> 3) & 7);
+    if (w >= S.N) return;
     const int A = S.A;
     stage_world<NT>(S, w, sh, tid);
     if (tid < 30) {       // lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent
@@ -225,7 +236,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             const Q toF = qinv(mrot);
             if (e == 0) {
                 if (step <= kNumPrepSteps) S.xPrep[row] = kNumPrepSteps - step;
-                float *so = S.xSelfObs + row * 13;
+                float *so = &sh.rows[i][kObsSelf];
                 store_posvel(so, mpos, quat_to_euler(mrot), qrot(toF, mlin), qrot(toF, mang));
                 so[12] = sh.grab[i] >= 0 ? 1.f : 0.f;
                 continue;
@@ -233,15 +244,15 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             int tslot; float *o; int width; bool present;
             if (e <= kMaxBoxes) {
                 const int b = e - 1; tslot = kBoxSlot0 + b; width = 17; present = b < nBoxes;
-                o = S.xBoxObs + (row * kMaxBoxes + b) * 17;
+                o = &sh.rows[i][kObsBoxes + b * 17];
             } else if (e <= kMaxBoxes + kMaxRamps) {
                 const int r = e - 1 - kMaxBoxes; tslot = kRampSlot0 + r; width = 14; present = r < nRamps;
-                o = S.xRampObs + (row * kMaxRamps + r) * 14;
+                o = &sh.rows[i][kObsRamps + r * 14];
             } else {
                 const int jj = e - 1 - kMaxBoxes - kMaxRamps;
                 const int j = jj < i ? jj : jj + 1;
                 tslot = kAgentSlot0 + j; width = 14; present = j < nAgents;
-                o = S.xAgentObs + (row * (kMaxAgents - 1) + jj) * 14;
+                o = &sh.rows[i][kObsAgents + jj * 14];
             }
             if (!present) { for (int k = 0; k < width; ++k) o[k] = 0.f; continue; }
             // computeRelativePosVelObs (sim.cpp:401-420)
@@ -291,6 +302,22 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             }
             for (; o < kMaxAgents; o += 2) { ga[o * 2] = 0.f; ga[o * 2 + 1] = 0.f; }
         }
+    }
+    __syncthreads();
+    // ---------------- the rows of the world's active agents -> exported columns, contiguous per column ----------------
+    // (rows of inactive agent slots are left as they are, as the per-item stores did)
+    {
+        const int row0 = w * A;
+        float *const dst[4] = {S.xSelfObs + (size_t)row0 * 13, S.xAgentObs + (size_t)row0 * 70, S.xBoxObs + (size_t)row0 * 153,
+                               S.xRampObs + (size_t)row0 * 28};
+        constexpr int width[4] = {13, (kMaxAgents - 1) * 14, kMaxBoxes * 17, kMaxRamps * 14};
+        constexpr int off[4] = {kObsSelf, kObsAgents, kObsBoxes, kObsRamps};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            for (int i = tid; i < nAgents * width[c]; i += NT) {
+                const int a = i / width[c], k = i - a * width[c];
+                dst[c][i] = sh.rows[a][off[c] + k];
+            }
     }
 }
 
