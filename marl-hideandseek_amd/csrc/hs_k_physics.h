@@ -872,6 +872,16 @@ HSD void physics_step(SimState &S, OctRes &R) {
 #pragma unroll 1
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect(S, R, NS);
+#ifdef HS_PRIO
+        // The launch ends with its slowest wave.  A wave shares its SIMD's issue slots with one other wave: the one
+        // with more contact work ahead of it (convex-test items are a good predictor) gets the higher priority.
+        if (sub == 0) {
+            const int load = ic.nbox + ic.nwedge;
+            if (load > HS_PRIO + 16) __builtin_amdgcn_s_setprio(3);
+            else if (load > HS_PRIO + 8) __builtin_amdgcn_s_setprio(2);
+            else if (load > HS_PRIO) __builtin_amdgcn_s_setprio(1);
+        }
+#endif
         HS_TICK(2)
         phase_sat(S, R, ic);
         HS_TICK(3)
