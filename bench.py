@@ -136,15 +136,31 @@ def main():
     # the kernels a step launches: k_physics (its tail is the per-step reset) and, unless skipped, k_observe
     skip_obs = bool(args.flags & (1 << 16))
     kms = {"physics": 0.0} if skip_obs else {"physics": 0.0, "observe": 0.0}
+    overlapped = False
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
         k = sim.last_step_kernel_ms()
-        for n in kms:
-            kms[n] += k[n]
+        kms["physics"] += k["physics"]
+        if not skip_obs:
+            overlapped = overlapped or k["observe"] < 0
+            kms["observe"] += max(k["observe"], 0.0)
     barrier()
     dt = time.perf_counter() - t0
+    obs_pass_steps = 0
+    if overlapped:
+        # Under the dependency schedule (the default) k_observe runs beside k_physics and has no duration of its own in
+        # the timed region; its kernel time comes from an extra, untimed pass with the two kernels launched one after
+        # the other (same results).  k_physics' events above are from the timed region.
+        sim.set_overlap(False)
+        kms["observe"] = 0.0
+        obs_pass_steps = min(args.steps, 240)
+        for _ in range(obs_pass_steps):
+            one_step()
+            kms["observe"] += sim.last_step_kernel_ms()["observe"]
+        kms["observe"] *= args.steps / max(obs_pass_steps, 1)
+        sim.set_overlap(True)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,7 +199,10 @@ def main():
                 "step": {"algorithmic_bytes_per_world_step": step_per_world,
                          "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                          "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                "kernel_ms_per_step": {n: kms[n] / max(args.steps, 1) for n in kms}}
+                "kernel_ms_per_step": {n: kms[n] / max(args.steps, 1) for n in kms},
+                "schedule": ("k_observe beside k_physics, octets in finish order (dependency schedule); k_physics timed "
+                             "in the timed region, k_observe in an extra pass of %d sequential steps" % obs_pass_steps)
+                if overlapped else "k_physics then k_observe on one stream"}
 
     if rank == 0:
         total_worlds = N * world_size

@@ -205,14 +205,23 @@ int32_t hs_train_interface(const hs_iface_entry **entries);
  *   dropped_dd_pairs / dropped_static_pairs: broadphase candidate pairs beyond the per-world capacities (16 body-body,
  *     24 body-static per substep) that were discarded — the oracle discards the same ones, so parity cannot see it.
  *     Sticky totals since hs_create.  hs_step still returns HS_OK; hs_last_error() carries a warning.
- *   graphs_in_use: 1 when HS_GRAPH=1 took effect and steps are replayed as HIP graphs. */
+ *   graphs_in_use: 1 when HS_GRAPH=1 took effect and steps are replayed as HIP graphs.
+ *   sched_error: non-zero when a bounded device-side wait of the dependency schedule expired (k_observe waiting for a
+ *     physics wave, or its gate): the blocking step that saw it returns HS_ERR_HIP, and so does the next call of an
+ *     asynchronous entry point — stale observations are never handed over as HS_OK. */
 typedef struct hs_device_status {
     int64_t dropped_dd_pairs;
     int64_t dropped_static_pairs;
     int32_t graphs_in_use;
-    int32_t reserved;
+    int32_t sched_error;
 } hs_device_status;
 int32_t hs_get_device_status(hs_sim *sim, hs_device_status *out);
+/* The dependency schedule between the two kernels of a step (k_observe beside k_physics, taking octets of worlds in
+ * the order physics finishes them) is on by default when the whole batch is resident on the device (<= 64 worlds per
+ * CU); 0 launches the kernels one after the other (what HS_OVERLAP=0 does for every handle).  Results are identical. */
+int32_t hs_set_overlap(hs_sim *sim, int32_t enabled);
+/* Test hook: plants `code` in the device-side sched_error word as an expired wait would. */
+int32_t hs_debug_inject_sched_error(hs_sim *sim, int32_t code);
 
 /* maxAgentsPerWorld (src/mgr.cpp:684). */
 int32_t hs_agents_per_world(const hs_sim *sim);

@@ -42,6 +42,14 @@ struct hs_sim {
     bool initialised = false;
     bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower than two direct launches)
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};     // physics, observe
+    // Dependency schedule (default on, HS_OVERLAP=0 or hs_set_overlap turn it off): k_observe is launched on its own
+    // stream beside k_physics and takes octets in the order their physics wave finishes.
+    bool overlap = true;
+    bool overlapped_last = false;          // the last launch used obs_stream
+    int slots = 0;                         // physics waves the device holds at once (8 per CU: LDS)
+    int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
+    hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t stream = nullptr;          // this handle's own stream: hs_init / hs_step / checkpoints run here
     hipEvent_t evIn = nullptr;             // orders `stream` after the device's legacy default stream (torch's writes to `action`)
     bool step_open = false;                // hs_step_begin without its hs_step_end
@@ -68,8 +76,9 @@ void set_desc(hs_sim *s, int id, void *ptr, int dtype, std::initializer_list<int
     for (; i < 4; ++i) d.dims[i] = 1;
 }
 
-void launch_observe(hs_sim *s, hipStream_t strm) {
-    const hs::SimState &S = s->S;
+void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
+    hs::SimState S = s->S;
+    S.stepPar = step_par;
     if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
     // one workgroup per world; the grid covers whole groups of 8 octets (k_observe's block -> world mapping)
     const int N = ((S.N + hs::kTile - 1) / hs::kTile + 7) / 8 * 64;
@@ -82,23 +91,53 @@ void launch_observe(hs_sim *s, hipStream_t strm) {
 }
 
 // One step = k_physics (movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results, reset: one
-// kernel, a wave per octet of 8 worlds, hs_k_physics.h) then k_observe.  Manager::init = k_reset
-// then k_observe.  `stages`: 1 physics, 2 reset (init only), 4 observe.
-int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7) {
-    const hs::SimState &S = s->S;
-    const int N = S.N;
+// kernel, a wave per octet of 8 worlds, hs_k_physics.h) and k_observe.  Manager::init = k_reset then k_observe.
+// `stages`: 1 physics, 2 reset (init only), 4 observe.
+//
+// Dependency schedule: the physics waves are independent and finish at very different times (an octet with many
+// contacts takes up to 1.8 x the time of a quiet one), so towards the end of k_physics most of the chip is idle.
+// k_observe is therefore launched on its own stream right away; its workgroups take octets in the order k_physics
+// finishes them and fill the slots that finished waves leave.  Only when every physics wave is resident from the
+// start (octets <= 8 per CU): then none of them ever waits for a slot that a waiting k_observe workgroup holds, and
+// k_gate keeps k_observe from starting before all of them have been placed.
+int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7, bool allow_overlap = false,
+                      bool host_joins = false) {
+    hs::SimState S = s->S;
+    const int N = S.N, noct = (N + hs::kTile - 1) / hs::kTile;
+    const bool skip_obs = (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
+    const bool overlap = allow_overlap && s->overlap && !first && stages == 7 && !skip_obs && noct <= s->slots;
+    S.stepPar = overlap ? s->sched_par : -1;
+    s->overlapped_last = false;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
+    // (a blocking hs_step has synchronised everything before and joins the two streams on the host: cross-stream
+    // event waits cost tens of microseconds each)
+    if (overlap && !host_joins) {
+        HS_HIP(hipEventRecord(s->evFork, strm));
+        HS_HIP(hipStreamWaitEvent(s->obs_stream, s->evFork, 0));
+    }
     if (!first && (stages & 1)) {
         // 17 body slots x 8 worlds need a third round of 64 lanes only with 6 agents per world
-        if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3((N + hs::kTile - 1) / hs::kTile), dim3(hs::kPhysThreads), 0, strm, S);
-        else hipLaunchKernelGGL(hs::k_physics<2>, dim3((N + hs::kTile - 1) / hs::kTile), dim3(hs::kPhysThreads), 0, strm, S);
+        if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3(noct), dim3(hs::kPhysThreads), 0, strm, S);
+        else hipLaunchKernelGGL(hs::k_physics<2>, dim3(noct), dim3(hs::kPhysThreads), 0, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
     if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
-    if (stages & 4) launch_observe(s, strm);
-    if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
+    if (overlap) {
+        hipLaunchKernelGGL(hs::k_gate, dim3(1), dim3(64), 0, s->obs_stream, S, noct);
+        launch_observe(s, s->obs_stream, s->sched_par);
+        if (prof) HS_HIP(hipEventRecord(s->ev[3], s->obs_stream));
+        if (!host_joins) {
+            HS_HIP(hipEventRecord(s->evJoin, s->obs_stream));
+            HS_HIP(hipStreamWaitEvent(strm, s->evJoin, 0));
+        }
+        s->overlapped_last = true;
+        s->sched_par ^= 1;
+    } else {
+        if (stages & 4) launch_observe(s, strm);
+        if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
+    }
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -108,8 +147,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
 // events between the graph launches.  It paid off while physics was ~40 launches per step; with the persistent
 // physics kernel a step is two launches and the direct launches are faster.  When capture or instantiation fails
 // the handle falls back to direct launches and hs_get_device_status reports graphs_in_use = 0.
-int launch_step(hs_sim *s, hipStream_t strm, bool first) {
-    if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling);
+int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false) {
+    if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling, 7, true, host_joins);
     const bool skip_obs = (s->S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
     const int ngraphs = skip_obs ? 1 : 2;
     if (!s->graph_exec[0]) {
@@ -145,6 +184,9 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
 int poll_status(hs_sim *s) {
     if (!s->host_flag || !*(volatile int *)s->host_flag) return HS_OK;
     HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
+    if (s->status_cache[2] != 0)
+        return fail(HS_ERR_HIP, "device-side wait of the dependency schedule expired (sched_error " +
+                                std::to_string(s->status_cache[2]) + "): the observations of this step are incomplete");
     g_err = "warning: broadphase candidate pairs beyond the per-world capacity were dropped (" +
             std::to_string(s->status_cache[0]) + " body-body, " + std::to_string(s->status_cache[1]) + " body-static so far)";
     return HS_OK;
@@ -221,6 +263,10 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
     HS_ALLOC(S.phaseTicks, 10 * (NP / hs::kTile));
+    { const size_t G = NP / hs::kTile;
+      if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
+      HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
+    S.stepPar = -1;
     HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
     if (hipHostMalloc((void **)&s->host_flag, 64, hipHostMallocMapped) != hipSuccess) { s->host_flag = nullptr; hs_destroy(s); return fail(HS_ERR_HIP, "hipHostMalloc failed"); }
@@ -239,8 +285,13 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
         if (hipEventCreate(&e) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipEventCreate failed"); }
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("HS_OVERLAP")) s->overlap = atoi(e) != 0;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->gpu_id) == hipSuccess) s->slots = 8 * prop.multiProcessorCount; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
+        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->obs_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
     S.wbeg = 0; S.wcnt = (int)N;
     std::memset(s->exports, 0, sizeof(s->exports));
     const int64_t n = (int64_t)N, r = (int64_t)R;
@@ -275,6 +326,9 @@ void hs_destroy(hs_sim *s) {
     hipDeviceSynchronize();
     for (void *p : s->allocs) hipFree(p);
     for (auto &e : s->ev) if (e) hipEventDestroy(e);
+    if (s->evFork) hipEventDestroy(s->evFork);
+    if (s->evJoin) hipEventDestroy(s->evJoin);
+    if (s->obs_stream) hipStreamDestroy(s->obs_stream);
     if (s->evIn) hipEventDestroy(s->evIn);
     if (s->stream) hipStreamDestroy(s->stream);
     if (s->host_flag) hipHostFree(s->host_flag);
@@ -310,7 +364,7 @@ int32_t hs_step_begin(hs_sim *s) {
     if (s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_step_begin: the previous step was not ended");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     int rc = order_after_default_stream(s);
-    if (rc == HS_OK) rc = launch_step(s, s->stream, false);
+    if (rc == HS_OK) rc = launch_step(s, s->stream, false, true);
     if (rc != HS_OK) return rc;
     s->step_open = true;
     return HS_OK;
@@ -322,8 +376,14 @@ int32_t hs_step_end(hs_sim *s) {
     s->step_open = false;
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     HS_HIP(hipStreamSynchronize(s->stream));
-    if (s->profiling)
-        for (int i = 0; i < 3; ++i) HS_HIP(hipEventElapsedTime(&s->last_ms[i], s->ev[i], s->ev[i + 1]));
+    if (s->overlapped_last) HS_HIP(hipStreamSynchronize(s->obs_stream));
+    if (s->profiling) {
+        HS_HIP(hipEventElapsedTime(&s->last_ms[0], s->ev[0], s->ev[1]));
+        HS_HIP(hipEventElapsedTime(&s->last_ms[1], s->ev[1], s->ev[2]));
+        // under the dependency schedule k_observe runs beside k_physics on another stream: it has no duration of its own
+        if (s->overlapped_last) s->last_ms[2] = -1.f;
+        else HS_HIP(hipEventElapsedTime(&s->last_ms[2], s->ev[2], s->ev[3]));
+    }
     return poll_status(s);
 }
 
@@ -335,7 +395,8 @@ int32_t hs_step(hs_sim *s) {
 int32_t hs_step_async(hs_sim *s, void *hip_stream) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    return launch_step(s, (hipStream_t)hip_stream, false);
+    int rc = poll_status(s);               // a failure of an earlier asynchronous step surfaces here
+    return rc != HS_OK ? rc : launch_step(s, (hipStream_t)hip_stream, false);
 }
 
 int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
@@ -470,7 +531,8 @@ int32_t hs_jax_step(hs_sim *s, void *hip_stream, void **buffers) {
     hipStream_t strm = (hipStream_t)hip_stream;
     const hs::SimState &S = s->S;
     const size_t N = (size_t)S.N, R = N * s->A;
-    int rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
+    int rc = poll_status(s);               // a failure of an earlier asynchronous step surfaces here
+    if (rc == HS_OK) rc = copy_dd(S.xAction, *buffers++, R * 5 * 4, strm);
     if (rc == HS_OK) rc = copy_dd(S.xReset, *buffers++, N * 4, strm);
     if (rc == HS_OK) rc = copy_dd(S.xPolicy, *buffers++, R * 4, strm);
     if (rc == HS_OK) rc = launch_step(s, strm, false);
@@ -616,6 +678,21 @@ int32_t hs_get_device_status(hs_sim *s, hs_device_status *out) {
     out->dropped_dd_pairs = s->status_cache[0];
     out->dropped_static_pairs = s->status_cache[1];
     out->graphs_in_use = (s->use_graph && s->graph_exec[0]) ? 1 : 0;
+    out->sched_error = s->status_cache[2];
+    return HS_OK;
+}
+
+int32_t hs_set_overlap(hs_sim *s, int32_t enabled) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    s->overlap = enabled != 0;
+    return HS_OK;
+}
+
+int32_t hs_debug_inject_sched_error(hs_sim *s, int32_t code) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipMemcpy(s->S.status + 2, &code, sizeof(code), hipMemcpyHostToDevice));
+    if (code != 0) *s->host_flag = 1;
     return HS_OK;
 }
 

@@ -809,6 +809,13 @@ HSD void physics_step(SimState &S, OctRes &R) {
     S.wbeg = o * kTile;
     S.wcnt = min(kTile, S.N - S.wbeg);
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
+    const int noct = gridDim.x;
+    if (S.stepPar >= 0 && L == 0) {                   // dependency schedule: clear the next step's half of the finish list
+        const int pn = S.stepPar ^ 1;
+        S.doneList[pn * noct + o] = -1;
+        if (o == 0) { S.doneTickets[pn] = 0; S.startedCount[pn] = 0; }
+        __hip_atomic_fetch_add(&S.startedCount[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef HS_PHASE_TIMING
     // development aid: wall-clock ticks (100 MHz) per phase of every octet -> S.phaseTicks[octet][10]
     long long tk = wall_clock64(); long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -920,6 +927,18 @@ HSD void physics_step(SimState &S, OctRes &R) {
     HS_TICK(8)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
     if (L < S.wcnt) reset_world(S, S.wbeg + L);
+    // Publish the octet to k_observe, which runs beside this kernel and takes finished octets in the order of this
+    // list: the wave's stores have left it (vmcnt), one lane releases at agent scope (the XCDs' L2s are not coherent
+    // with each other) and appends the octet.
+    if (S.stepPar >= 0) {
+        mem_sync();
+        if (L == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(&S.doneTickets[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&S.doneList[S.stepPar * noct + ticket], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef HS_PHASE_TIMING
     if (L == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[(size_t)o * 10 + i] += acc[i];
 #endif
@@ -930,6 +949,17 @@ template <int ROUNDS>
 __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     __shared__ OctRes R;
     physics_step<ROUNDS>(S, R);
+}
+
+// Holds the stream of k_observe back until every wave of k_physics has started, i.e. holds its slot on a CU: the
+// waiting k_observe workgroups that follow can then never keep a physics wave from being placed.  One wave.
+__global__ void __launch_bounds__(64) k_gate(SimState S, int noct) {
+    if (threadIdx.x != 0) return;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(&S.startedCount[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= noct) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    S.status[2] = 2; *S.hostFlag = 1;      // (never observed; keeps a bug from hanging the GPU)
 }
 
 }  // namespace hs

@@ -69,7 +69,13 @@ struct SimState {
     // --- contact-manifold workspace of the physics kernel (hs_k_physics.h): written by the lane that ran the convex
     // test, read by the lanes that solve the contact; [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS (L2-resident)
     void *wsDD, *wsSC;
-    int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, -, -
+    // --- dependency schedule between k_physics and k_observe (hideseek.hip launch_step): octets in the order their
+    // physics wave finished, double-buffered by step parity
+    int *doneList;         // [2][octets]  -1 = not finished yet
+    int *doneTickets;      // [2]
+    int *startedCount;     // [2] physics waves that have started (k_gate holds k_observe back until all have)
+    int stepPar;           // parity of this step, or -1: k_observe does not wait (init, checkpoints, sequential launches)
+    int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, expired wait, -
                            // (include/hideseek.h hs_device_status); bumped only when something happens
     int *hostFlag;         // pinned host word (device-visible): set to 1 together with any change of status
     long long *phaseTicks; // [octets][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)

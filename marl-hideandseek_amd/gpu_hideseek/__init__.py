@@ -239,7 +239,11 @@ class HideAndSeekSimulator:
         _check(self._L.hs_get_device_status(self._h, C.byref(st)))
         return {"dropped_dd_pairs": int(st.dropped_dd_pairs), "dropped_static_pairs": int(st.dropped_static_pairs),
                 "dropped_candidate_pairs": int(st.dropped_dd_pairs + st.dropped_static_pairs),
-                "graphs_in_use": bool(st.graphs_in_use)}
+                "graphs_in_use": bool(st.graphs_in_use), "sched_error": int(st.sched_error)}
+
+    def set_overlap(self, enabled):
+        """hs_set_overlap: the dependency schedule between k_physics and k_observe (default on); results are identical."""
+        _check(self._L.hs_set_overlap(self._h, int(bool(enabled))))
 
     def warning(self):
         """The library's last message for this thread (a warning after a successful call, e.g. dropped pairs)."""

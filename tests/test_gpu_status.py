@@ -47,6 +47,67 @@ def test_dropped_candidate_pairs_are_counted_and_reported():
     assert st[1:3] == ["0", "0"], out
 
 
+def test_sched_error_turns_into_an_error_code():
+    """hs_debug_inject_sched_error plants what an expired wait of the dependency schedule writes; the blocking step
+    and the next asynchronous call must both fail instead of handing stale observations over as HS_OK."""
+    import torch
+    import gpu_hideseek
+    sim = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=64, sim_flags=0, rand_seed=1,
+        min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+    sim.init()
+    sim.step()
+    assert sim.device_status()["sched_error"] == 0
+    assert sim._L.hs_debug_inject_sched_error(sim._h, 1) == 0
+    with pytest.raises(RuntimeError, match="wait .* expired"):
+        sim.step()
+    strm = torch.cuda.Stream()
+    with pytest.raises(RuntimeError, match="wait .* expired"):
+        sim.step_async(strm.cuda_stream)
+    assert sim.device_status()["sched_error"] == 1
+    assert sim._L.hs_debug_inject_sched_error(sim._h, 0) == 0
+    sim.step()
+
+
+DIGEST_LOOP = """
+import hashlib, torch, gpu_hideseek
+sim = gpu_hideseek.HideAndSeekSimulator(exec_mode=1, gpu_id=0, num_worlds=%d, sim_flags=0, rand_seed=9, min_hiders=2,
+      max_hiders=%d, min_seekers=2, max_seekers=%d, num_pbt_policies=1)
+sim.init()
+strm = torch.cuda.Stream()
+act = sim.action_tensor().to_torch()
+h = hashlib.sha256()
+for s in range(%d):
+    g = torch.arange(act.shape[0], device=act.device)
+    act[:, 0] = ((g * 7 + s) %% 10 - 5).int(); act[:, 1] = ((g * 3 + 2 * s) %% 10 - 5).int()
+    if %d:
+        strm.wait_stream(torch.cuda.current_stream())
+        sim.step_async(strm.cuda_stream)
+        strm.synchronize()
+    else:
+        sim.step()
+    if s %% 5 == 4:
+        for n in ("lidar", "self_data", "box_data", "reward", "visible_agents_mask", "global_positions"):
+            h.update(getattr(sim, n + "_tensor")().to_torch().cpu().numpy().tobytes())
+b, m = sim.debug_bodies()
+h.update(b.tobytes())
+print("DIGEST", h.hexdigest(), sim.device_status()["sched_error"])
+"""
+
+
+@pytest.mark.parametrize("worlds,hiders,seekers,steps,async_", [(900, 2, 2, 25, 0), (900, 2, 2, 25, 1), (16000, 2, 2, 12, 0),
+                                                               (16384, 3, 3, 8, 1), (131, 3, 3, 30, 0)])
+def test_dependency_schedule_gives_identical_results(worlds, hiders, seekers, steps, async_):
+    """k_observe beside k_physics, taking octets in the order physics finishes them (the default), against the two
+    kernels launched one after the other (HS_OVERLAP=0): observations at every 5th step and the final state agree bit
+    for bit — blocking steps and the stream entry point, the benchmark's world count, a full 16 384-world shard of
+    BASELINE configs[3] with 6 agents, and a world count that ends in a partial octet."""
+    code = DIGEST_LOOP % (worlds, hiders, seekers, steps, async_)
+    a = [l for l in _child(code, {"HS_OVERLAP": "1"}).splitlines() if l.startswith("DIGEST")][0]
+    b = [l for l in _child(code, {"HS_OVERLAP": "0"}).splitlines() if l.startswith("DIGEST")][0]
+    assert a == b and a.split()[2] == "0"
+
+
 def test_graph_mode_is_visible():
     out = _child(STEP_LOOP, {"HS_GRAPH": "1"})
     assert [l for l in out.splitlines() if l.startswith("STATUS")][0].split()[3] == "1", out
