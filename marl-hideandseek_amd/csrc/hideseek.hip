@@ -105,7 +105,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     hs::SimState S = s->S;
     const int N = S.N, noct = (N + hs::kTile - 1) / hs::kTile;
     const bool skip_obs = (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
-    const bool overlap = allow_overlap && s->overlap && !first && stages == 7 && !skip_obs && noct <= s->slots;
+    // (8 slots of slack: k_gate and the first k_observe workgroups must never take a slot that a physics wave still needs)
+    const bool overlap = allow_overlap && s->overlap && !first && stages == 7 && !skip_obs && noct + 8 <= s->slots;
     S.stepPar = overlap ? s->sched_par : -1;
     s->overlapped_last = false;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));

@@ -187,14 +187,20 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta) {
 // box-only items in .x and of items that involve a ramp (wedge hull) in .y; the ramp items start at the next
 // multiple of 32 so that most rounds of the convex test run the box code only.
 struct ItemCounts { int nbox, nwedge; };
+template <int JB>            // body slots per lane: 2 covers 16 slots (<= 5 agents), 3 all 17
 HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
-    constexpr int G = 8, JB = (kNumDSlots + G - 1) / G;
+    constexpr int G = 8;
     const int L = threadIdx.x, g = L / G, l = L % G;
     const int o = blockIdx.x;
-    // the octet's walls -> LDS (rows beyond a world's count are never read)
-    for (int i = L; i < 4 * kLdsWalls * kTile; i += 64) {
-        const int c = i / (kLdsWalls * kTile), r = i - c * (kLdsWalls * kTile);       // r = wall * 8 + world
-        (&R.u.det.wall[0][0][0])[i] = S.walls.octet(o)[c * (kMaxWalls * kTile) + r];
+    // the octet's walls -> LDS, 16 bytes per lane and component (rows beyond a world's count are never read)
+    {
+        static_assert(kLdsWalls * kTile == 4 * 64, "one float4 per lane per component");
+        const float *src = S.walls.octet(o);
+        float4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *(const float4 *)(src + c * (kMaxWalls * kTile) + 4 * L);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(float4 *)(&R.u.det.wall[c][0][0] + 4 * L) = v[c];
     }
     if (l == 0) { R.scAcc[g] = 0u; R.ddAcc[g] = 0u; }
     wave_sync();
@@ -810,6 +816,9 @@ HSD void physics_step(SimState &S, OctRes &R) {
     S.wcnt = min(kTile, S.N - S.wbeg);
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
     const int noct = gridDim.x;
+    // The launch ends with its slowest wave, and under the dependency schedule k_observe's workgroups run on the same
+    // SIMDs beside the physics waves that are still at work: those keep the first claim on the issue slots.
+    __builtin_amdgcn_s_setprio(3);
     if (S.stepPar >= 0 && L == 0) {                   // dependency schedule: clear the next step's half of the finish list
         const int pn = S.stepPar ^ 1;
         S.doneList[pn * noct + o] = -1;
@@ -878,17 +887,7 @@ HSD void physics_step(SimState &S, OctRes &R) {
     HS_TICK(1)
 #pragma unroll 1
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
-        const ItemCounts ic = phase_detect(S, R, NS);
-#ifdef HS_PRIO
-        // The launch ends with its slowest wave.  A wave shares its SIMD's issue slots with one other wave: the one
-        // with more contact work ahead of it (convex-test items are a good predictor) gets the higher priority.
-        if (sub == 0) {
-            const int load = ic.nbox + ic.nwedge;
-            if (load > HS_PRIO + 16) __builtin_amdgcn_s_setprio(3);
-            else if (load > HS_PRIO + 8) __builtin_amdgcn_s_setprio(2);
-            else if (load > HS_PRIO) __builtin_amdgcn_s_setprio(1);
-        }
-#endif
+        const ItemCounts ic = phase_detect<ROUNDS>(S, R, NS);
         HS_TICK(2)
         phase_sat(S, R, ic);
         HS_TICK(3)
