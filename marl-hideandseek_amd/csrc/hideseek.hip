@@ -13,6 +13,7 @@
 #include "hs_k_reset.h"
 #include "hs_k_observe.h"
 #include "hs_k_physics.h"
+#include "hs_k_balance.h"
 #include "hs_solver.h"
 
 namespace {
@@ -50,6 +51,11 @@ struct hs_sim {
     int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
     hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // Load balancing between the physics waves (hs_k_balance.h; HS_BALANCE=0 turns it off, HS_BALANCE_PERIOD sets the steps between deals)
+    bool balance = true;
+    int balance_period = 32, steps_since_balance = 0;
+    int *bal_hist = nullptr, *bal_cursor = nullptr, *bal_new_slot = nullptr;
+    void *bal_tmp = nullptr; size_t bal_tmp_bytes = 0;
     hipStream_t stream = nullptr;          // this handle's own stream: hs_init / hs_step / checkpoints run here
     hipEvent_t evIn = nullptr;             // orders `stream` after the device's legacy default stream (torch's writes to `action`)
     bool step_open = false;                // hs_step_begin without its hs_step_end
@@ -143,12 +149,47 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     return HS_OK;
 }
 
+// Deal the worlds to the octets by contact load (hs_k_balance.h): a handful of small launches every balance_period steps.
+template <typename T, int ROWS>
+int balance_move(hs_sim *s, hipStream_t strm, const hs::Col<T, ROWS> &col, int nfull) {
+    const size_t bytes = (size_t)ROWS * ((s->S.N + hs::kTile - 1) / hs::kTile * hs::kTile) * sizeof(T);
+    HS_HIP(hipMemcpyAsync(s->bal_tmp, col.p, bytes, hipMemcpyDeviceToDevice, strm));
+    const int n = nfull * ROWS;
+    hipLaunchKernelGGL(hs::k_balance_move<T>, dim3((n + 255) / 256), dim3(256), 0, strm, col.p, (const T *)s->bal_tmp, ROWS,
+                       (const int *)s->S.slotOfWorld, (const int *)s->bal_new_slot, nfull);
+    return HS_OK;
+}
+int balance_worlds(hs_sim *s, hipStream_t strm) {
+    const hs::SimState &S = s->S;
+    const int nfull = S.N / hs::kTile * hs::kTile;
+    if (nfull < 2 * hs::kTile) return HS_OK;
+    const dim3 grid((nfull + 255) / 256), blk(256);
+    hipLaunchKernelGGL(hs::k_balance_hist, grid, blk, 0, strm, S, nfull, s->bal_hist);
+    hipLaunchKernelGGL(hs::k_balance_scan, dim3(1), dim3(hs::kBalanceBins), 0, strm, s->bal_hist, s->bal_cursor);
+    hipLaunchKernelGGL(hs::k_balance_deal, grid, blk, 0, strm, S, nfull, s->bal_cursor, s->bal_new_slot);
+    int rc;
+    if ((rc = balance_move(s, strm, S.bpos, nfull)) != HS_OK || (rc = balance_move(s, strm, S.brot, nfull)) != HS_OK ||
+        (rc = balance_move(s, strm, S.blin, nfull)) != HS_OK || (rc = balance_move(s, strm, S.bang, nfull)) != HS_OK ||
+        (rc = balance_move(s, strm, S.bmeta, nfull)) != HS_OK || (rc = balance_move(s, strm, S.aforce, nfull)) != HS_OK ||
+        (rc = balance_move(s, strm, S.walls, nfull)) != HS_OK || (rc = balance_move(s, strm, S.planes, nfull)) != HS_OK ||
+        (rc = balance_move(s, strm, S.runningScores, nfull)) != HS_OK || (rc = balance_move(s, strm, S.grabOther, nfull)) != HS_OK ||
+        (rc = balance_move(s, strm, S.grabData, nfull)) != HS_OK) return rc;
+    hipLaunchKernelGGL(hs::k_balance_commit, grid, blk, 0, strm, S, nfull, (const int *)s->bal_new_slot);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 // Optional (HS_GRAPH=1): the step as two HIP graphs (physics, observe), captured once on a private stream (the
 // legacy stream cannot be captured) and replayed on the caller's stream; the profiling events stay ordinary stream
 // events between the graph launches.  It paid off while physics was ~40 launches per step; with the persistent
 // physics kernel a step is two launches and the direct launches are faster.  When capture or instantiation fails
 // the handle falls back to direct launches and hs_get_device_status reports graphs_in_use = 0.
 int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false) {
+    if (!first && s->balance && ++s->steps_since_balance >= s->balance_period) {
+        s->steps_since_balance = 0;
+        int rc = balance_worlds(s, strm);
+        if (rc != HS_OK) return rc;
+    }
     if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling, 7, true, host_joins);
     const bool skip_obs = (s->S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
     const int ngraphs = skip_obs ? 1 : 2;
@@ -205,8 +246,13 @@ struct HostCol {
         HS_HIP(hipMemcpy(v.data(), c.p, v.size() * sizeof(T), hipMemcpyDeviceToHost));
         return HS_OK;
     }
-    T operator()(size_t row, size_t w) const { return v[((w >> 3) * ROWS + row) * hs::kTile + (w & 7)]; }
+    T operator()(size_t row, size_t p) const { return v[((p >> 3) * ROWS + row) * hs::kTile + (p & 7)]; }     // p = slot
 };
+int load_slots(hs_sim *s, std::vector<int32_t> &slot) {
+    slot.resize(s->S.N);
+    HS_HIP(hipMemcpy(slot.data(), s->S.slotOfWorld, slot.size() * 4, hipMemcpyDeviceToHost));
+    return HS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -268,6 +314,9 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
       if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
       HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
     S.stepPar = -1;
+    HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N);
+    HS_ALLOC(s->bal_hist, hs::kBalanceBins); HS_ALLOC(s->bal_cursor, hs::kBalanceBins); HS_ALLOC(s->bal_new_slot, N);
+    { char *tmp; s->bal_tmp_bytes = (size_t)S.walls.kRows * NP * sizeof(float); HS_ALLOC(tmp, s->bal_tmp_bytes); s->bal_tmp = tmp; }
     HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
     if (hipHostMalloc((void **)&s->host_flag, 64, hipHostMallocMapped) != hipSuccess) { s->host_flag = nullptr; hs_destroy(s); return fail(HS_ERR_HIP, "hipHostMalloc failed"); }
@@ -275,8 +324,11 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     if (hipHostGetDevicePointer((void **)&S.hostFlag, s->host_flag, 0) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipHostGetDevicePointer failed"); }
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
-        std::vector<int32_t> ones(N, 1), neg(AG * NP, -1);
-        if (hipMemcpy(S.xReset, ones.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        std::vector<int32_t> ones(N, 1), neg(AG * NP, -1), ident(NP);
+        for (size_t i = 0; i < NP; ++i) ident[i] = i < N ? (int32_t)i : -1;      // slot == world until k_balance deals them
+        if (hipMemcpy(S.slotOfWorld, ident.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(S.worldOfSlot, ident.data(), NP * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(S.xReset, ones.data(), N * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(S.grabOther.p, neg.data(), AG * NP * 4, hipMemcpyHostToDevice) != hipSuccess) {
             hs_destroy(s);
             return fail(HS_ERR_HIP, "initial upload failed");
@@ -287,6 +339,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HS_OVERLAP")) s->overlap = atoi(e) != 0;
+    if (const char *e = getenv("HS_BALANCE")) s->balance = atoi(e) != 0;
+    if (const char *e = getenv("HS_BALANCE_PERIOD")) { const int v = atoi(e); if (v > 0) s->balance_period = v; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->gpu_id) == hipSuccess) s->slots = 8 * prop.multiProcessorCount; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess ||
@@ -584,12 +638,15 @@ int32_t hs_debug_dump_bodies(hs_sim *s, float *bodies, int32_t *meta) {
     int rc;
     if ((rc = pos.load(s->S.bpos, N)) != HS_OK || (rc = rot.load(s->S.brot, N)) != HS_OK || (rc = lin.load(s->S.blin, N)) != HS_OK ||
         (rc = ang.load(s->S.bang, N)) != HS_OK || (rc = m.load(s->S.bmeta, N)) != HS_OK) return rc;
+    std::vector<int32_t> slot;
+    if ((rc = load_slots(s, slot)) != HS_OK) return rc;
     for (size_t w = 0; w < N; ++w)
         for (size_t i = 0; i < D; ++i) {
+            const size_t p = (size_t)slot[w];
             float *o = bodies + (w * D + i) * 13;
-            for (size_t c = 0; c < 3; ++c) { o[c] = pos(c * D + i, w); o[7 + c] = lin(c * D + i, w); o[10 + c] = ang(c * D + i, w); }
-            for (size_t c = 0; c < 4; ++c) o[3 + c] = rot(c * D + i, w);
-            int32_t mm = m(i, w);
+            for (size_t c = 0; c < 3; ++c) { o[c] = pos(c * D + i, p); o[7 + c] = lin(c * D + i, p); o[10 + c] = ang(c * D + i, p); }
+            for (size_t c = 0; c < 4; ++c) o[3 + c] = rot(c * D + i, p);
+            int32_t mm = m(i, p);
             int32_t *om = meta + (w * D + i) * 3;
             if (mm == 0) { om[0] = -1; om[1] = 2; om[2] = 0; }
             else { om[0] = (mm & 0xff) - 1; om[1] = (mm >> 8) & 0xff; om[2] = (mm >> 16) & 0xff; }
@@ -610,10 +667,12 @@ int32_t hs_debug_dump_walls(hs_sim *s, float *walls, int32_t *info) {
     HS_HIP(hipMemcpy(np.data(), s->S.numPlanes, N * 4, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(cnt.data(), s->S.counts, N * 4, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(step.data(), s->S.curEpisodeStep, N * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> slot;
+    if ((rc = load_slots(s, slot)) != HS_OK) return rc;
     for (size_t w = 0; w < N; ++w) {
         for (size_t k = 0; k < K; ++k)
             for (size_t c = 0; c < 4; ++c)
-                walls[(w * K + k) * 4 + c] = (int)k < nw[w] ? wl(c * K + k, w) : 0.f;
+                walls[(w * K + k) * 4 + c] = (int)k < nw[w] ? wl(c * K + k, (size_t)slot[w]) : 0.f;
         int32_t *m = info + w * 8;
         const int c = cnt[w];
         m[0] = nw[w]; m[1] = np[w]; m[2] = (c >> 12) & 15; m[3] = (c >> 16) & 15; m[4] = c & 15; m[5] = (c >> 4) & 15;

@@ -51,30 +51,29 @@ HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
 
 // Cooperative load of one world's geometry from the SoA columns into LDS.
 template <int NT>
-HSD void stage_world(const SimState &S, int w, ObsShared<NT> &sh, int tid) {
-    const int N = S.N;
-    for (int i = tid; i < kNumDSlots; i += NT) sh.g.meta[i] = S.bmeta(i, w);
+HSD void stage_world(const SimState &S, int w, int ps, ObsShared<NT> &sh, int tid) {
+    for (int i = tid; i < kNumDSlots; i += NT) sh.g.meta[i] = S.bmeta(i, ps);
     for (int i = tid; i < kNumDSlots * 3; i += NT) {
         int c = i / kNumDSlots, s = i % kNumDSlots;
-        sh.g.pos[s][c] = S.bpos(c * kNumDSlots + s, w);
-        sh.lin[s][c] = S.blin(c * kNumDSlots + s, w);
-        sh.ang[s][c] = S.bang(c * kNumDSlots + s, w);
+        sh.g.pos[s][c] = S.bpos(c * kNumDSlots + s, ps);
+        sh.lin[s][c] = S.blin(c * kNumDSlots + s, ps);
+        sh.ang[s][c] = S.bang(c * kNumDSlots + s, ps);
     }
     for (int i = tid; i < kNumDSlots * 4; i += NT) {
         int c = i / kNumDSlots, s = i % kNumDSlots;
-        sh.g.rot[s][c] = S.brot(c * kNumDSlots + s, w);
+        sh.g.rot[s][c] = S.brot(c * kNumDSlots + s, ps);
     }
     const int nw = S.numWalls[w], np = S.numPlanes[w];
     if (tid == 0) { sh.g.numWalls = nw; sh.g.numPlanes = np; sh.nPairs = 0; }
     for (int i = tid; i < nw * 4; i += NT) {
         int c = i / nw, k = i % nw;
-        sh.g.wall[k][c] = S.walls(c * kMaxWalls + k, w);
+        sh.g.wall[k][c] = S.walls(c * kMaxWalls + k, ps);
     }
     for (int i = tid; i < np * 4; i += NT) {
         int c = i / np, p = i % np;
-        sh.g.plane[p][c] = S.planes(c * kMaxPlanes + p, w);
+        sh.g.plane[p][c] = S.planes(c * kMaxPlanes + p, ps);
     }
-    for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther(i, w);
+    for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther(i, ps);
 }
 
 HSD unsigned long long ray_key(float t, int id) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id; }
@@ -89,6 +88,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     // blocks b, b + 8, ..., b + 56 (same XCD under round-robin placement) take the 8 worlds of one octet
     const int blk = blockIdx.x;
     int oct = ((blk >> 6) << 3) + (blk & 7);
+    if (oct >= (S.N + kTile - 1) / kTile) return;        // (the grid covers whole groups of 8 octets)
     if (S.stepPar >= 0) {
         // Dependency schedule (hideseek.hip launch_step): `oct` counts finished octets — this workgroup takes a world
         // of the oct-th octet whose physics wave FINISHES, and waits for it: one relaxed poll loop by one lane (bounded,
@@ -96,7 +96,6 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         // resident before this kernel starts (k_gate) and never waits for anything, so the wait always ends.
         __shared__ int sh_oct;
         const int noct = (S.N + kTile - 1) / kTile;
-        if (oct >= noct) return;
         if (tid == 0) {
             const int *slot = &S.doneList[S.stepPar * noct + oct];
             int v = -1;
@@ -114,10 +113,11 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         oct = sh_oct;
         if (oct < 0) return;
     }
-    const int w = oct * kTile + ((blk >> 3) & 7);
-    if (w >= S.N) return;
+    const int p = oct * kTile + ((blk >> 3) & 7);       // slot in the tiled columns
+    const int w = S.worldOfSlot[p];                      // the world that lives there (exports, per-world scalars)
+    if (w < 0) return;
     const int A = S.A;
-    stage_world<NT>(S, w, sh, tid);
+    stage_world<NT>(S, w, p, sh, tid);
     if (tid < 30) {       // lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent
         float theta = 2.f * kPi * ((float)tid / 30.f) + kPi / 2.f;
         hs_sincosf(theta, &sh.lidarSin[tid], &sh.lidarCos[tid]);

@@ -70,6 +70,7 @@ struct alignas(16) OctRes {
     unsigned char wallBodies[kNumDSlots * kTile];   // bodies with a wall / extra-plane manifold in this substep
     unsigned char actGL[kMaxAgents][kTile];     // grab / lock requests
     unsigned char numWalls[kTile], numPlanes[kTile], ndd[kTile], nsc[kTile], seen[kTile], hasGrab[kTile];
+    int wid[kTile];                             // world id of each slot of the octet (SimState::worldOfSlot), -1 = empty slot
 };
 static_assert(sizeof(OctRes) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
 static_assert(sizeof(((OctRes *)0)->u.sat) <= sizeof(((OctRes *)0)->u.det) &&
@@ -317,7 +318,11 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         }
         if (slot < NS) R.scInfo[slot][g] = (unsigned short)(asc[jb] > 0 ? (bsc[jb] | (asc[jb] << 8)) : 0);
     }
-    if (l == 0) { R.ndd[g] = (unsigned char)min(tot_dd, kMaxDDCand); R.nsc[g] = (unsigned char)min(tot_sc, kMaxSCand); }
+    if (l == 0) {
+        R.ndd[g] = (unsigned char)min(tot_dd, kMaxDDCand); R.nsc[g] = (unsigned char)min(tot_sc, kMaxSCand);
+        // what k_balance sorts the worlds by: candidate pairs are where an octet's time differs from another's
+        if (R.wid[g] >= 0 && tot_dd + tot_sc > 0) S.loadAcc[R.wid[g]] += tot_dd + tot_sc;
+    }
     wave_sync();
     return ic;
 }
@@ -456,12 +461,12 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
     constexpr int GL = 8;
     const int L = threadIdx.x, g = L / GL, q = L % GL;
     const int gbit0 = g * GL;                                     // first lane of this group in the wave
-    const int w = S.wbeg + g;
+    const int w = S.wbeg + g;                                     // the world's slot in the tiled columns
     const int ndd = R.ndd[g];
     const bool grab = R.hasGrab[g] != 0;
     if (__ballot(R.ddAcc[g] != 0u || (POS && grab)) == 0ull) return;        // nothing to do in the whole octet
     if (POS && grab && q == 0) {
-        const int teams = S.teams[w];
+        const int teams = S.teams[R.wid[g]];
         for (int a = 0; a < kMaxAgents; ++a) {
             if (!team_agent_active(teams, a)) continue;
             const int other = S.grabOther(a, w);
@@ -693,9 +698,9 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
     bool need_action = false;
     if (L < kMaxAgents * kTile) {
         const int agent = L / kTile, g = L % kTile;
-        const int w = S.wbeg + g;
+        const int w = R.wid[g], p = S.wbeg + g;          // world id (exports, per-world scalars) / slot (columns)
         int fl = 0;
-        if (agent < A_ && g < S.wcnt) {
+        if (agent < A_ && w >= 0) {
             const int teams = S.teams[w], step = S.curEpisodeStep[w];
             const bool active = team_agent_active(teams, agent) != 0;
             const int type = team_agent_type(teams, agent);
@@ -706,8 +711,8 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
                 if (instant) { fx = 400.f * (float)(ax - 2); fy = 400.f * (float)(ay - 2); tz = 120.f * (float)(ar - 2); }
                 else { fx = 12.f * (float)(ax - 5); fy = 12.f * (float)(ay - 5); tz = 3.f * (float)(ar - 5); }
                 V3 f = qrot(rld4(R.rot, kAgentSlot0 + agent, g), {fx, fy, 0.f});
-                S.aforce(0 * kMaxAgents + agent, w) = f.x; S.aforce(1 * kMaxAgents + agent, w) = f.y;
-                S.aforce(2 * kMaxAgents + agent, w) = f.z; S.aforce(3 * kMaxAgents + agent, w) = tz;
+                S.aforce(0 * kMaxAgents + agent, p) = f.x; S.aforce(1 * kMaxAgents + agent, p) = f.y;
+                S.aforce(2 * kMaxAgents + agent, p) = f.z; S.aforce(3 * kMaxAgents + agent, p) = tz;
                 fl = (ag == 1 ? 1 : 0) | (al == 1 ? 2 : 0);
                 act_row[0] = 2; act_row[1] = 2; act_row[2] = 2; act_row[3] = 0; act_row[4] = 0;   // sim.cpp:365-369
             }
@@ -717,15 +722,15 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
     }
     const bool any = __ballot(need_action) != 0ull;
     wave_sync();                          // actGL and the forces (global memory) are in place
-    if (any && L < S.wcnt) {              // one lane per world: the ray casts of a world are sequential
+    if (any && L < kTile && R.wid[L] >= 0) {   // one lane per world: the ray casts of a world are sequential
         bool want = false;
         for (int a = 0; a < A_; ++a) want |= R.actGL[a][L] != 0;
-        if (want) action_system(S, R, L, A_, S.teams[S.wbeg + L]);
+        if (want) action_system(S, R, L, A_, S.teams[R.wid[L]]);
     }
     // worlds with a grab joint take part in the body-body phase of every substep
     if (L < kTile) {
         bool grab = false;
-        if (L < S.wcnt) for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther(a, S.wbeg + L) >= 0;
+        if (R.wid[L] >= 0) for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther(a, S.wbeg + L) >= 0;
         R.hasGrab[L] = grab ? 1 : 0;
     }
     wave_sync();
@@ -736,9 +741,9 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
 HSD void phase_post(const SimState &S, OctRes &R) {
     constexpr int G = 8;
     const int L = threadIdx.x, g = L / G, l = L % G;
-    const int w = S.wbeg + g;
+    const int w = R.wid[g], p = S.wbeg + g;          // world id (exports, per-world scalars) / slot (columns)
     const int A_ = S.A;
-    const bool wok = g < S.wcnt;
+    const bool wok = w >= 0;
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     int teams = 0, step = 0, counts = 0;
     if (wok) {
@@ -757,7 +762,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
     for (int pr = l; wok && step >= kNumPrepSteps - 1 && pr < 9; pr += G) {      // (seeker, hider) pairs
         const int si = pr / 3, hi_ = pr % 3;
         if (si < cnt_seekers(counts) && hi_ < cnt_hiders(counts)) {
-            const ResGeom geom = {R, S, g, w};
+            const ResGeom geom = {R, S, g, p};
             const int ss = kAgentSlot0 + team_seeker(teams, si), hs_ = kAgentSlot0 + team_hider(teams, hi_);
             const V3 spos = geom.g_pos(ss);
             const V3 fwd = qrot(geom.g_rot(ss), {0.f, 1.f, 0.f});
@@ -788,7 +793,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
     }
     if (l == 0) {
         float *res = S.xEpisodeResult + w * 2;
-        int s0 = S.runningScores(0, w), s1 = S.runningScores(1, w);
+        int s0 = S.runningScores(0, p), s1 = S.runningScores(1, p);
         if (step == 0) { res[0] = 0.f; res[1] = 0.f; s0 = 0; s1 = 0; }
         if (step >= kNumPrepSteps) {
             const bool hidden = hider_reward == 1.f;
@@ -801,7 +806,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
             else if (s0 < s1) { res[0] = 0.f; res[1] = 1.f; }
             else { res[0] = 0.5f; res[1] = 0.5f; }
         }
-        S.runningScores(0, w) = s0; S.runningScores(1, w) = s1;
+        S.runningScores(0, p) = s0; S.runningScores(1, p) = s1;
         S.hiderTeamReward[w] = hider_reward;
     }
 }
@@ -812,8 +817,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
 template <int ROUNDS>
 HSD void physics_step(SimState &S, OctRes &R) {
     const int L = threadIdx.x, o = blockIdx.x;
-    S.wbeg = o * kTile;
-    S.wcnt = min(kTile, S.N - S.wbeg);
+    S.wbeg = o * kTile;                               // first slot of the octet in the tiled columns
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
     const int noct = gridDim.x;
     // The launch ends with its slowest wave, and under the dependency schedule k_observe's workgroups run on the same
@@ -837,9 +841,10 @@ HSD void physics_step(SimState &S, OctRes &R) {
     copy_in(&R.lin[0][0][0], S.blin, o); copy_in(&R.ang[0][0][0], S.bang, o);
     copy_in(&R.meta[0][0], S.bmeta, o);
     if (L < kTile) {
-        const bool ok = L < S.wcnt;
-        R.numWalls[L] = ok ? (unsigned char)S.numWalls[S.wbeg + L] : 0;
-        R.numPlanes[L] = ok ? (unsigned char)S.numPlanes[S.wbeg + L] : 0;
+        const int w = S.worldOfSlot[S.wbeg + L];      // which world lives in this slot (k_balance moves them)
+        R.wid[L] = w;
+        R.numWalls[L] = w >= 0 ? (unsigned char)S.numWalls[w] : 0;
+        R.numPlanes[L] = w >= 0 ? (unsigned char)S.numPlanes[w] : 0;
         R.seen[L] = 0; R.ndd[L] = 0; R.nsc[L] = 0;
     }
     if (L < 4 * kTile) (&R.plane0[0][0])[L] = S.planes((L >> 3) * kMaxPlanes, S.wbeg + (L & 7));
@@ -925,7 +930,7 @@ HSD void physics_step(SimState &S, OctRes &R) {
     mem_sync();                           // the write-back is complete before a regenerated level overwrites it
     HS_TICK(8)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
-    if (L < S.wcnt) reset_world(S, S.wbeg + L);
+    if (L < kTile && R.wid[L] >= 0) reset_world(S, R.wid[L]);
     // Publish the octet to k_observe, which runs beside this kernel and takes finished octets in the order of this
     // list: the wave's stores have left it (vmcnt), one lane releases at agent scope (the XCDs' L2s are not coherent
     // with each other) and appends the octet.

@@ -315,6 +315,7 @@ HSD void gen_debug(GenWorld &g, int level) {                    // level_gen.cpp
 template <bool LOAD>
 HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoint *ck) {
     const int N = S.N;
+    const int ps = S.slotOfWorld[w];        // the world's slot in the tiled columns (hs_state.h)
     uint32_t ep, world_id;
     if (LOAD) {
         ep = ck->episode_key[0]; world_id = ck->episode_key[1];
@@ -358,31 +359,31 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
     if (!LOAD) S.hiderTeamReward[w] = 1.f;        // resetSystem sim.cpp:199; the load graph leaves it alone
     S.numWalls[w] = g.numWalls; S.numPlanes[w] = g.numPlanes;
     for (int i = 0; i < g.numWalls; ++i) {
-        S.walls(0 * kMaxWalls + i, w) = g.wcx[i]; S.walls(1 * kMaxWalls + i, w) = g.wcy[i];
-        S.walls(2 * kMaxWalls + i, w) = g.whx[i]; S.walls(3 * kMaxWalls + i, w) = g.why[i];
+        S.walls(0 * kMaxWalls + i, ps) = g.wcx[i]; S.walls(1 * kMaxWalls + i, ps) = g.wcy[i];
+        S.walls(2 * kMaxWalls + i, ps) = g.whx[i]; S.walls(3 * kMaxWalls + i, ps) = g.why[i];
     }
     for (int p = 0; p < g.numPlanes; ++p) {
-        S.planes(0 * kMaxPlanes + p, w) = g.pn[p].x; S.planes(1 * kMaxPlanes + p, w) = g.pn[p].y;
-        S.planes(2 * kMaxPlanes + p, w) = g.pn[p].z; S.planes(3 * kMaxPlanes + p, w) = g.pd[p];
+        S.planes(0 * kMaxPlanes + p, ps) = g.pn[p].x; S.planes(1 * kMaxPlanes + p, ps) = g.pn[p].y;
+        S.planes(2 * kMaxPlanes + p, ps) = g.pn[p].z; S.planes(3 * kMaxPlanes + p, ps) = g.pd[p];
     }
     for (int i = 0; i < kNumDSlots; ++i) {
-        S.bmeta(i, w) = g.obj[i] == OBJ_NONE ? 0 : meta_pack(g.obj[i], g.resp[i], g.owner[i]);
-        S.bpos(0 * kNumDSlots + i, w) = g.pos[i].x; S.bpos(1 * kNumDSlots + i, w) = g.pos[i].y;
-        S.bpos(2 * kNumDSlots + i, w) = g.pos[i].z;
-        S.brot(0 * kNumDSlots + i, w) = g.rot[i].w; S.brot(1 * kNumDSlots + i, w) = g.rot[i].x;
-        S.brot(2 * kNumDSlots + i, w) = g.rot[i].y; S.brot(3 * kNumDSlots + i, w) = g.rot[i].z;
-        S.blin(0 * kNumDSlots + i, w) = g.lin[i].x; S.blin(1 * kNumDSlots + i, w) = g.lin[i].y;
-        S.blin(2 * kNumDSlots + i, w) = g.lin[i].z;
-        S.bang(0 * kNumDSlots + i, w) = 0.f; S.bang(1 * kNumDSlots + i, w) = 0.f;
-        S.bang(2 * kNumDSlots + i, w) = 0.f;
+        S.bmeta(i, ps) = g.obj[i] == OBJ_NONE ? 0 : meta_pack(g.obj[i], g.resp[i], g.owner[i]);
+        S.bpos(0 * kNumDSlots + i, ps) = g.pos[i].x; S.bpos(1 * kNumDSlots + i, ps) = g.pos[i].y;
+        S.bpos(2 * kNumDSlots + i, ps) = g.pos[i].z;
+        S.brot(0 * kNumDSlots + i, ps) = g.rot[i].w; S.brot(1 * kNumDSlots + i, ps) = g.rot[i].x;
+        S.brot(2 * kNumDSlots + i, ps) = g.rot[i].y; S.brot(3 * kNumDSlots + i, ps) = g.rot[i].z;
+        S.blin(0 * kNumDSlots + i, ps) = g.lin[i].x; S.blin(1 * kNumDSlots + i, ps) = g.lin[i].y;
+        S.blin(2 * kNumDSlots + i, ps) = g.lin[i].z;
+        S.bang(0 * kNumDSlots + i, ps) = 0.f; S.bang(1 * kNumDSlots + i, ps) = 0.f;
+        S.bang(2 * kNumDSlots + i, ps) = 0.f;
     }
     int teams = 0;
     for (int i = 0; i < 3; ++i) { teams |= (g.hiders[i] & 7) << (3 * i); teams |= (g.seekers[i] & 7) << (9 + 3 * i); }
     for (int i = 0; i < kMaxAgents; ++i) {
         teams |= (g.agentType[i] & 1) << (18 + i);
         if (i < g.numActiveAgents) teams |= 1 << (24 + i);
-        S.grabOther(i, w) = -1;
-        for (int c = 0; c < 4; ++c) S.aforce(c * kMaxAgents + i, w) = 0.f;
+        S.grabOther(i, ps) = -1;
+        for (int c = 0; c < 4; ++c) S.aforce(c * kMaxAgents + i, ps) = 0.f;
     }
     S.teams[w] = teams;
     S.counts[w] = cnt_pack(g.numHiders, g.numSeekers, g.numActiveAgents, g.numActiveBoxes, g.numActiveRamps, g.seekersFirst);
@@ -402,14 +403,14 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
     }
     if (!LOAD) return;
     // ---- loadCheckpointSystem sim.cpp:973, 985-1043
-    S.runningScores(0, w) = ck->running_scores[0]; S.runningScores(1, w) = ck->running_scores[1];
+    S.runningScores(0, ps) = ck->running_scores[0]; S.runningScores(1, ps) = ck->running_scores[1];
     auto put_body = [&](int slot, const float *b) {       // pos3 rot4 lin3 ang3
         for (int c = 0; c < 3; ++c) {
-            S.bpos(c * kNumDSlots + slot, w) = b[c];
-            S.blin(c * kNumDSlots + slot, w) = b[7 + c];
-            S.bang(c * kNumDSlots + slot, w) = b[10 + c];
+            S.bpos(c * kNumDSlots + slot, ps) = b[c];
+            S.blin(c * kNumDSlots + slot, ps) = b[7 + c];
+            S.bang(c * kNumDSlots + slot, ps) = b[10 + c];
         }
-        for (int c = 0; c < 4; ++c) S.brot(c * kNumDSlots + slot, w) = b[3 + c];
+        for (int c = 0; c < 4; ++c) S.brot(c * kNumDSlots + slot, ps) = b[3 + c];
     };
     const int nb = ck->num_boxes < 0 ? 0 : (ck->num_boxes > g.numActiveBoxes ? g.numActiveBoxes : ck->num_boxes);
     const int nr = ck->num_ramps < 0 ? 0 : (ck->num_ramps > g.numActiveRamps ? g.numActiveRamps : ck->num_ramps);
@@ -417,19 +418,19 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
         const hs_ckpt_object &o = i < nb ? ck->boxes[i] : ck->ramps[i - nb];
         const int slot = i < nb ? i : kRampSlot0 + (i - nb);
         put_body(slot, o.pos);
-        S.bmeta(slot, w) = meta_pack(g.obj[slot], o.is_locked ? RESP_STATIC : RESP_DYNAMIC, (int)(o.team & 3u));
+        S.bmeta(slot, ps) = meta_pack(g.obj[slot], o.is_locked ? RESP_STATIC : RESP_DYNAMIC, (int)(o.team & 3u));
     }
     for (int i = 0; i < g.numHiders + g.numSeekers; ++i) {
         const hs_ckpt_agent &a = ck->agents[i];
         const int ai = i < g.numHiders ? g.hiders[i] : g.seekers[i - g.numHiders];
         put_body(kAgentSlot0 + ai, a.pos);
         if (a.grab_idx >= 0 && a.grab_idx < nb + nr) {
-            S.grabOther(ai, w) = a.grab_idx < nb ? a.grab_idx : kRampSlot0 + (a.grab_idx - nb);
+            S.grabOther(ai, ps) = a.grab_idx < nb ? a.grab_idx : kRampSlot0 + (a.grab_idx - nb);
             float gd[kGrabWords] = {a.grab_r2[0], a.grab_r2[1], a.grab_r2[2],
                                     a.attach_rot2[0], a.attach_rot2[1], a.attach_rot2[2], a.attach_rot2[3], a.separation,
                                     a.grab_r1[0], a.grab_r1[1], a.grab_r1[2],
                                     a.attach_rot1[0], a.attach_rot1[1], a.attach_rot1[2], a.attach_rot1[3]};
-            for (int c = 0; c < kGrabWords; ++c) S.grabData(c * kMaxAgents + ai, w) = gd[c];
+            for (int c = 0; c < kGrabWords; ++c) S.grabData(c * kMaxAgents + ai, ps) = gd[c];
         }
     }
 }
@@ -471,31 +472,32 @@ __global__ void __launch_bounds__(64) k_save_ckpt(SimState S) {
     if (w >= N) return;
     if (S.xCkptCtrl[w] == 0) return;
     S.xCkptCtrl[w] = 0;
+    const int ps = S.slotOfWorld[w];
     hs_checkpoint *ck = (hs_checkpoint *)S.xCkpt + w;
     uint32_t *raw = (uint32_t *)ck;
     for (int i = 0; i < (int)(sizeof(hs_checkpoint) / 4); ++i) raw[i] = 0u;
     ck->episode_key[0] = S.epKeyA[w]; ck->episode_key[1] = S.epKeyB[w];
-    ck->running_scores[0] = S.runningScores(0, w); ck->running_scores[1] = S.runningScores(1, w);
+    ck->running_scores[0] = S.runningScores(0, ps); ck->running_scores[1] = S.runningScores(1, ps);
     ck->episode_step = S.curEpisodeStep[w];
     const int cnt = S.counts[w], teams = S.teams[w];
     const int nh = cnt_hiders(cnt), ns = cnt_seekers(cnt), nb = cnt_boxes(cnt), nr = cnt_ramps(cnt);
     auto get_body = [&](int slot, float *b) {
         for (int c = 0; c < 3; ++c) {
-            b[c] = S.bpos(c * kNumDSlots + slot, w);
-            b[7 + c] = S.blin(c * kNumDSlots + slot, w);
-            b[10 + c] = S.bang(c * kNumDSlots + slot, w);
+            b[c] = S.bpos(c * kNumDSlots + slot, ps);
+            b[7 + c] = S.blin(c * kNumDSlots + slot, ps);
+            b[10 + c] = S.bang(c * kNumDSlots + slot, ps);
         }
-        for (int c = 0; c < 4; ++c) b[3 + c] = S.brot(c * kNumDSlots + slot, w);
+        for (int c = 0; c < 4; ++c) b[3 + c] = S.brot(c * kNumDSlots + slot, ps);
     };
     for (int i = 0; i < nh + ns; ++i) {
         const int ai = i < nh ? team_hider(teams, i) : team_seeker(teams, i - nh);
         hs_ckpt_agent &a = ck->agents[i];
         get_body(kAgentSlot0 + ai, a.pos);
         a.grab_idx = -1;
-        const int other = S.grabOther(ai, w);
+        const int other = S.grabOther(ai, ps);
         if (other >= 0) {
             float gd[kGrabWords];
-            for (int c = 0; c < kGrabWords; ++c) gd[c] = S.grabData(c * kMaxAgents + ai, w);
+            for (int c = 0; c < kGrabWords; ++c) gd[c] = S.grabData(c * kMaxAgents + ai, ps);
             for (int c = 0; c < 3; ++c) { a.grab_r2[c] = gd[c]; a.grab_r1[c] = gd[8 + c]; }
             for (int c = 0; c < 4; ++c) { a.attach_rot2[c] = gd[3 + c]; a.attach_rot1[c] = gd[11 + c]; }
             a.separation = gd[7];
@@ -508,7 +510,7 @@ __global__ void __launch_bounds__(64) k_save_ckpt(SimState S) {
         const int slot = i < nb ? i : kRampSlot0 + (i - nb);
         hs_ckpt_object &o = i < nb ? ck->boxes[i] : ck->ramps[i - nb];
         get_body(slot, o.pos);
-        const int m = S.bmeta(slot, w);
+        const int m = S.bmeta(slot, ps);
         o.team = (uint32_t)meta_owner(m);
         o.is_locked = meta_resp(m) == RESP_STATIC ? 1 : 0;
     }

@@ -33,7 +33,13 @@ struct SimState {
     RandKey initKey;       // rand::initKey(seed) (src/mgr.cpp:678)
     int minHiders, maxHiders, minSeekers, maxSeekers;
     int worldOffset;
-    int wbeg, wcnt;        // the octet's first world and world count (set inside k_physics)
+    int wbeg, wcnt;        // the octet's first slot (set inside k_physics)
+    // --- which world lives where.  The tiled columns are indexed by SLOT; per-world scalars and the exported tensors
+    // by WORLD id.  Initially slot == world; k_balance (hs_k_balance.h) deals the worlds to the octets by contact load
+    // so that the physics waves — one per octet, the launch ends with the slowest — carry about the same work.
+    int *slotOfWorld;      // [N]
+    int *worldOfSlot;      // [ceil(N / 8) * 8]  -1 = empty slot (padding of the last octet)
+    int *loadAcc;          // [N] candidate pairs seen since the last k_balance
 
     // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
     Col<float, 3 * kNumDSlots> bpos;       // row = component * 17 + slot
