@@ -366,13 +366,18 @@ HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, con
     return 4;
 }
 
-// Two lanes of a wave — lane L and lane L + 32, `hi` on the second — run this together on the SAME pair:
-// the kernel is bound by the length of one lane's instruction stream, and the axis tests split cleanly.  The low
-// lane tests A's face normals and the first half of the edge-direction pairs, its partner B's face normals and
-// the second half; they exchange results with cross-lane shuffles and combine them exactly as the sequential
-// loop would (strictly-greater updates, earlier axis wins ties).  Contact generation then runs on the low
-// lane only (it owns the LDS clip scratch); the partner returns false.
-HSD bool collide_hulls(const HullSrc &sa, const HullSrc &sb, const ClipBuf &cb, RawManifold &m, const bool hi) {
+// The convex test in two stages, so that the (long, single-lane) contact generation runs only for the pairs that do
+// collide, compacted over the wave's items, and neither stage has to keep the other's registers.
+//
+// Stage 1, sat_axes: the separating-axis search.  Two lanes of a wave — lane L and lane L + 32, `hi` on the second —
+// run it together on the SAME pair: the low lane tests A's face normals and the first half of the edge-direction
+// pairs, its partner B's face normals and the second half; they exchange results with cross-lane shuffles and
+// combine them exactly as the sequential loop would (strictly-greater updates, earlier axis wins ties).  The result
+// is valid on the low lane:  code 0 = separated;  1 | ea << 4 | eb << 8 = edge contact along `ax`;
+// 2 | face << 4 | refB << 8 = face contact with reference face `face` of B (refB) or A.
+struct AxisResult { int code; V3 ax; };
+HSD AxisResult sat_axes(const HullSrc &sa, const HullSrc &sb, const bool hi) {
+    AxisResult res = {0, {0.f, 0.f, 0.f}};
     // ---- face normals: this lane takes the faces of X against the vertices of Y (X = A on the low lane, B on its partner)
     float bestA, bestB; int fa, fb;
     {
@@ -389,7 +394,7 @@ HSD bool collide_hulls(const HullSrc &sa, const HullSrc &sb, const ClipBuf &cb, 
             if (fx < 0 || s > best) { best = s; fx = f; }
         }
         const float best_o = __shfl_xor(best, 32); const int fx_o = __shfl_xor(fx, 32);
-        if (sep | __shfl_xor(sep, 32)) return false;
+        if (sep | __shfl_xor(sep, 32)) return res;
         bestA = hi ? best_o : best; fa = hi ? fx_o : fx;
         bestB = hi ? best : best_o; fb = hi ? fx : fx_o;
     }
@@ -415,45 +420,53 @@ HSD bool collide_hulls(const HullSrc &sa, const HullSrc &sb, const ClipBuf &cb, 
             if (s > 0.f) { sep = 1; break; }
             if (ea < 0 || s > bestE) { bestE = s; ea = i; eb = j; axE = ax; }
         }
-        if (sep | __shfl_xor(sep, 32)) return false;
+        if (sep | __shfl_xor(sep, 32)) return res;
         const float bE_o = __shfl_xor(bestE, 32); const int ea_o = __shfl_xor(ea, 32), eb_o = __shfl_xor(eb, 32);
         const V3 ax_o = {__shfl_xor(axE.x, 32), __shfl_xor(axE.y, 32), __shfl_xor(axE.z, 32)};
-        if (hi) return false;                 // the low lane goes on alone
+        if (hi) return res;                   // the low lane holds the result
         // sequential semantics: the second half replaces the first half's best only if strictly greater
         if (ea_o >= 0 && (ea < 0 || bE_o > bestE)) { bestE = bE_o; ea = ea_o; eb = eb_o; axE = ax_o; }
     }
-    float bestF = fmaxf(bestA, bestB);
-    if (ea >= 0 && bestE > 0.9f * bestF + 0.0025f) {
-        int sa = -1, sb = -1; float va = 0.f, vb = 0.f;
+    const float bestF = fmaxf(bestA, bestB);
+    if (ea >= 0 && bestE > 0.9f * bestF + 0.0025f) { res.code = 1 | (ea << 4) | (eb << 8); res.ax = axE; return res; }
+    const bool refB = bestB > 0.98f * bestA + 0.00125f;
+    res.code = 2 | ((refB ? fb : fa) << 4) | ((refB ? 1 : 0) << 8);
+    return res;
+}
+
+// Stage 2, sat_contact: contact generation for a colliding pair, one lane (it owns a slice of the LDS clip scratch):
+// the closest points of the two supporting edges, or the incident face clipped against the reference face.
+HSD bool sat_contact(const HullSrc &sa, const HullSrc &sb, const AxisResult &res, const ClipBuf &cb, RawManifold &m) {
+    if ((res.code & 3) == 1) {
+        const HullRef A = hull_from(sa), B = hull_from(sb);
+        const int ea = (res.code >> 4) & 15, eb = (res.code >> 8) & 15;
+        const V3 axE = res.ax;
+        int ia = -1, ib = -1; float va = 0.f, vb = 0.f;
         const int ane = hull_ne(A), bne = hull_ne(B);
         for (int e = 0; e < ane; ++e) {
             int v0, v1, dir; hull_edge(A, e, &v0, &v1, &dir);
             if (dir != ea) continue;
             float p = dot(axE, hull_v(A, v0)) + dot(axE, hull_v(A, v1));
-            if (sa < 0 || p > va) { va = p; sa = e; }
+            if (ia < 0 || p > va) { va = p; ia = e; }
         }
         for (int e = 0; e < bne; ++e) {
             int v0, v1, dir; hull_edge(B, e, &v0, &v1, &dir);
             if (dir != eb) continue;
             float p = dot(axE, hull_v(B, v0)) + dot(axE, hull_v(B, v1));
-            if (sb < 0 || p < vb) { vb = p; sb = e; }
+            if (ib < 0 || p < vb) { vb = p; ib = e; }
         }
         int a0, a1, b0, b1, dd;
-        hull_edge(A, sa, &a0, &a1, &dd); hull_edge(B, sb, &b0, &b1, &dd);
+        hull_edge(A, ia, &a0, &a1, &dd); hull_edge(B, ib, &b0, &b1, &dd);
         V3 c1, c2;
         closest_seg_seg(hull_v(A, a0), hull_v(A, a1), hull_v(B, b0), hull_v(B, b1), &c1, &c2);
         m.n = axE; m.np = 1; m.pA[0] = c1; m.pB[0] = c2;
         return true;
     }
-    // face contact: pick the reference hull first so that the (long) clipping code runs once per wave
-    // whichever body owns the reference face
+    // face contact: the reference hull is chosen first so that the clipping code runs once whichever body owns the face
     V3 pinc[4]; float dist[4];
-    const bool refB = bestB > 0.98f * bestA + 0.00125f;
-    HullRef R, I;
-    R.kind = refB ? B.kind : A.kind; I.kind = refB ? A.kind : B.kind;
-    R.c = vsel(refB, B.c, A.c); R.ax = vsel(refB, B.ax, A.ax); R.ay = vsel(refB, B.ay, A.ay); R.az = vsel(refB, B.az, A.az); R.e = vsel(refB, B.e, A.e);
-    I.c = vsel(refB, A.c, B.c); I.ax = vsel(refB, A.ax, B.ax); I.ay = vsel(refB, A.ay, B.ay); I.az = vsel(refB, A.az, B.az); I.e = vsel(refB, A.e, B.e);
-    const int fr = refB ? fb : fa;
+    const bool refB = ((res.code >> 8) & 1) != 0;
+    const int fr = (res.code >> 4) & 15;
+    const HullRef R = hull_from(hull_src_sel(refB, sb, sa)), I = hull_from(hull_src_sel(refB, sa, sb));
     const V3 nr = hull_fn(R, fr);
     const int c = clip_face_contact(R, fr, nr, I, cb, pinc, dist);
     if (c == 0) return false;

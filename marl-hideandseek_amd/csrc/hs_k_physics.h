@@ -58,6 +58,7 @@ struct alignas(16) OctRes {
         struct {
             float clip[kClipWords];                                     // polygon clipping of the convex tests
             unsigned short items[kMaxItems + 32];                       // world << 6 | candidate (32+ = static); ramp items start at a multiple of 32
+            int pend[5][kClipLanes];                                    // colliding pairs waiting for contact generation: item, axis code, axis xyz
         } sat;
     } u;
     unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 8
@@ -73,8 +74,7 @@ struct alignas(16) OctRes {
     int wid[kTile];                             // world id of each slot of the octet (SimState::worldOfSlot), -1 = empty slot
 };
 static_assert(sizeof(OctRes) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
-static_assert(sizeof(((OctRes *)0)->u.sat) <= sizeof(((OctRes *)0)->u.det) &&
-              offsetof(OctRes, u.sat.items) >= offsetof(OctRes, u.det.wall), "items must not overlap the AABBs");
+static_assert(offsetof(OctRes, u.sat.items) >= offsetof(OctRes, u.det.wall), "items must not overlap the AABBs");
 
 // ---- accessors of the resident columns ----
 template <int C> HSD V3 rld3(const float (&a)[C][kNumDSlots][kTile], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g]}; }
@@ -328,90 +328,128 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Exact convex tests.  Two lanes per item: lane L < 32 and lane L + 32 run the test of the same pair together
-// (collide_hulls); the low lane owns the clip scratch and writes the manifold.
-HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
-    static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
-    const int wedge0 = (ic.nbox + 31) / 32 * 32;
-    const int total = ic.nwedge > 0 ? wedge0 + ic.nwedge : ic.nbox;
+// Exact convex tests, in two stages (hs_collide.h).  Stage 1 — the separating-axis search — runs over all the
+// octet's candidate pairs, two lanes per pair (L and L + 32), 32 pairs per round; the pairs that collide are appended
+// to a pending list.  Stage 2 — contact generation, the long part: polygon clipping on one lane — runs on the pending
+// pairs only, compacted, 32 per round: about a third of the candidates collide, so one round serves the whole octet.
+HSD HullSrc sat_hull_a(const OctRes &R, int g, int a) { return hull_src_body(meta_obj(R.meta[a][g]), rld3(R.pos, a, g), rld4(R.rot, a, g)); }
+HSD HullSrc sat_hull_b(const SimState &S, const OctRes &R, int g, int w, bool isdd, int bsel) {
+    if (isdd) return hull_src_body(meta_obj(R.meta[bsel][g]), rld3(R.pos, bsel, g), rld4(R.rot, bsel, g));
+    // (the staged walls share their LDS with the clip buffers: from global memory here)
+    return hull_src_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
+                         S.walls(2 * kMaxWalls + bsel, w), S.walls(3 * kMaxWalls + bsel, w));
+}
+// stage 2 for the first `npend` pending pairs: lane i < 32 takes pair i
+HSD void sat_flush(const SimState &S, OctRes &R, int npend) {
     const int lane = threadIdx.x & 63;
-    const bool hi = lane >= kClipLanes;
-    const ClipBuf cb = {R.u.sat.clip, lane & (kClipLanes - 1)};
-    for (int it = lane & (kClipLanes - 1); it < total; it += kClipLanes) {
-        if (it >= ic.nbox && it < wedge0) continue;
-        const int item = R.u.sat.items[it];
+    if (lane < npend) {
+        const int item = R.u.sat.pend[0][lane];
+        AxisResult res;
+        res.code = R.u.sat.pend[1][lane];
+        res.ax = {__int_as_float(R.u.sat.pend[2][lane]), __int_as_float(R.u.sat.pend[3][lane]), __int_as_float(R.u.sat.pend[4][lane])};
         const int g = item >> 6, idx = item & 63;
         const int w = S.wbeg + g;
         const bool isdd = idx < 32;
         const int kk = idx & 31;
         const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
         const int a = pair & 0xff, bsel = pair >> 8;
-        ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
-        ManS *const wsSC = (ManS *)S.wsSC + (size_t)w * kMaxSCand;
-        const int oa = meta_obj(R.meta[a][g]);
-        const V3 pa = rld3(R.pos, a, g);
-        const Q qa = rld4(R.rot, a, g);
+        const ClipBuf cb = {R.u.sat.clip, lane};
         RawManifold raw;
-        if (!isdd && bsel >= kMaxWalls) {
-            const int p = bsel - kMaxWalls;
-            const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
-            if (!hi && collide_hull_plane(hull_ref_body(oa, pa, qa), pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
-                ManS m;
-                m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
-                m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
-                m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
+        if (sat_contact(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), res, cb, raw)) {
+            const int oa = meta_obj(R.meta[a][g]);
+            const int ob = isdd ? meta_obj(R.meta[bsel][g]) : OBJ_WALL;
+            const V3 pa = rld3(R.pos, a, g);
+            const Q qai = qinv(rld4(R.rot, a, g));
+            const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
+            if (isdd) {
+                ManDD m;
+                m.a = a; m.b = bsel; m.np = raw.np; m.muS = muS; m.muD = muD;
+                st3(m.n, raw.n);
+                const V3 pb = rld3(R.pos, bsel, g);
+                const Q qbi = qinv(rld4(R.rot, bsel, g));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool on = j < raw.np;
-                    st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
+                    st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                    st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
+                    m.lam[j] = 0.f;
+                }
+                ((ManDD *)S.wsDD + (size_t)w * kMaxDDCand)[kk] = m;
+                atomicOr(&R.ddAcc[g], 1u << kk);
+            } else {
+                ManS m;
+                m.np = raw.np; m.muS = muS; m.muD = muD; m.pad[0] = 0.f; m.pad[1] = 0.f;
+                st3(m.n, raw.n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = j < raw.np;
+                    st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
                     m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                 }
-                wsSC[kk] = m;
+                ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m;
                 atomicOr(&R.scAcc[g], 1u << kk);
             }
-            continue;
-        }
-        int ob; V3 pb = {0.f, 0.f, 0.f}; Q qb = {1.f, 0.f, 0.f, 0.f};
-        HullSrc hb;
-        if (isdd) {
-            ob = meta_obj(R.meta[bsel][g]); pb = rld3(R.pos, bsel, g); qb = rld4(R.rot, bsel, g);
-            hb = hull_src_body(ob, pb, qb);
-        } else {
-            ob = OBJ_WALL;      // (the staged walls share their LDS with the clip buffers: from global memory here)
-            hb = hull_src_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
-                               S.walls(2 * kMaxWalls + bsel, w), S.walls(3 * kMaxWalls + bsel, w));
-        }
-        if (!collide_hulls(hull_src_body(oa, pa, qa), hb, cb, raw, hi)) continue;
-        const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
-        const Q qai = qinv(qa);
-        if (isdd) {
-            ManDD m;
-            m.a = a; m.b = bsel; m.np = raw.np; m.muS = muS; m.muD = muD;
-            st3(m.n, raw.n);
-            const Q qbi = qinv(qb);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool on = j < raw.np;
-                st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
-                st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
-                m.lam[j] = 0.f;
-            }
-            wsDD[kk] = m;
-            atomicOr(&R.ddAcc[g], 1u << kk);
-        } else {
-            ManS m;
-            m.np = raw.np; m.muS = muS; m.muD = muD; m.pad[0] = 0.f; m.pad[1] = 0.f;
-            st3(m.n, raw.n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool on = j < raw.np;
-                st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
-                m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
-            }
-            wsSC[kk] = m;
-            atomicOr(&R.scAcc[g], 1u << kk);
         }
     }
+    wave_sync();
+}
+HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
+    static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
+    const int wedge0 = (ic.nbox + 31) / 32 * 32;
+    const int total = ic.nwedge > 0 ? wedge0 + ic.nwedge : ic.nbox;
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= kClipLanes;
+    int npend = 0;
+    for (int base = 0; base < total; base += kClipLanes) {
+        const int it = base + (lane & (kClipLanes - 1));
+        AxisResult res = {0, {0.f, 0.f, 0.f}};
+        int item = 0;
+        if (it < total && !(it >= ic.nbox && it < wedge0)) {
+            item = R.u.sat.items[it];
+            const int g = item >> 6, idx = item & 63;
+            const int w = S.wbeg + g;
+            const bool isdd = idx < 32;
+            const int kk = idx & 31;
+            const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
+            const int a = pair & 0xff, bsel = pair >> 8;
+            if (!isdd && bsel >= kMaxWalls) {
+                // extra planes (debug levels only): hull against plane, no axis search
+                const int oa = meta_obj(R.meta[a][g]);
+                const int p = bsel - kMaxWalls;
+                const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
+                RawManifold raw;
+                if (!hi && collide_hull_plane(hull_ref_body(oa, rld3(R.pos, a, g), rld4(R.rot, a, g)), pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
+                    ManS m;
+                    m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
+                    m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
+                    m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = j < raw.np;
+                        st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
+                        m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
+                    }
+                    ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m;
+                    atomicOr(&R.scAcc[g], 1u << kk);
+                }
+            } else {
+                res = sat_axes(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), hi);
+            }
+        }
+        // the colliding pairs of this round join the pending list (their low lanes hold the results)
+        const bool hit = !hi && res.code != 0;
+        const unsigned long long m = __ballot(hit);
+        const int nhit = __popcll(m);
+        if (npend + nhit > kClipLanes) { wave_sync(); sat_flush(S, R, npend); npend = 0; }
+        if (hit) {
+            const int pos = npend + __popcll(m & ((1ull << lane) - 1ull));
+            R.u.sat.pend[0][pos] = item; R.u.sat.pend[1][pos] = res.code;
+            R.u.sat.pend[2][pos] = __float_as_int(res.ax.x); R.u.sat.pend[3][pos] = __float_as_int(res.ax.y); R.u.sat.pend[4][pos] = __float_as_int(res.ax.z);
+        }
+        npend += nhit;
+    }
+    wave_sync();
+    if (npend > 0) sat_flush(S, R, npend);
     mem_sync();           // the manifolds (global memory) are complete for the lanes that solve them
 }
 
