@@ -245,6 +245,9 @@ int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
  * [groups][10] = pre, integrate, detect, sat, dd_pos, body_pos, dd_vel, body_vel, post, -; all zero unless the
  * library was built with -DHS_PHASE_TIMING.  Returns the number of groups written (<= max_groups). */
 int32_t hs_debug_phase_ticks(hs_sim *sim, int64_t *out, int32_t max_groups);
+/* The same for k_observe: ticks per section, summed over all waves: stage (incl. the schedule's wait), per-agent table,
+ * ray setup, walls, planes, hull cull, exact hull tests, ray results, observation rows. */
+int32_t hs_debug_observe_ticks(hs_sim *sim, int64_t out[16]);
 
 /* Profiling aid: one dword-per-lane coalesced copy of `bytes` bytes (read + write), used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */

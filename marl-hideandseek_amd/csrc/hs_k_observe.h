@@ -42,6 +42,8 @@ struct ObsShared {
     unsigned short pairs[kMaxPairs];                       // ray << 5 | body slot
     int nPairs;
     float lidarSin[30], lidarCos[30];                      // hs_sincosf of the 30 lidar angles, once per workgroup
+    // per (agent, body slot): origin - body position and |.|^2 - bounding radius^2, shared by the agent's 46 rays
+    float rel[kAgents][kNumDSlots][4];
 };
 
 HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
@@ -85,6 +87,13 @@ template <int NT>
 __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     __shared__ ObsShared<NT> sh;
     const int tid = threadIdx.x;
+#ifdef HS_PHASE_TIMING
+    long long otk = wall_clock64();
+    long long *const oacc = S.phaseTicks + (size_t)10 * ((S.N + kTile - 1) / kTile) + (blockIdx.x & 1023) * 16;
+#define HS_OTICK(i) { const long long now_ = wall_clock64(); if ((tid & 63) == 0) atomicAdd((unsigned long long *)&oacc[i], (unsigned long long)(now_ - otk)); otk = now_; }
+#else
+#define HS_OTICK(i)
+#endif
     // blocks b, b + 8, ..., b + 56 (same XCD under round-robin placement) take the 8 worlds of one octet
     const int blk = blockIdx.x;
     int oct = ((blk >> 6) << 3) + (blk & 7);
@@ -129,6 +138,16 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     const WorldGeom &g = sh.g;
     const int nAgents = cnt_agents(counts), nBoxes = cnt_boxes(counts), nRamps = cnt_ramps(counts);
     const int nRays = A * kRaysPerAgent;
+    HS_OTICK(0)
+    for (int item = tid; item < nAgents * kNumDSlots; item += NT) {
+        const int i = item / kNumDSlots, b = item % kNumDSlots;
+        const V3 mo = geom_pos(g, kAgentSlot0 + i) - geom_pos(g, b);
+        const int m = g.meta[b];
+        sh.rel[i][b][0] = mo.x; sh.rel[i][b][1] = mo.y; sh.rel[i][b][2] = mo.z;
+        sh.rel[i][b][3] = dot(mo, mo) - obj_bound_r2(meta_obj(m));
+    }
+    __syncthreads();
+    HS_OTICK(1)
 
     // ---------------- pass 1: ray setup, walls + planes, cull against the movable hulls ----------------
     for (int r = tid; r < nRays; r += NT) {
@@ -160,15 +179,26 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         }
         sh.rayO[r][0] = o.x; sh.rayO[r][1] = o.y; sh.rayO[r][2] = o.z;
         sh.rayD[r][0] = d.x; sh.rayD[r][1] = d.y; sh.rayD[r][2] = d.z;
+        HS_OTICK(2)
         // static geometry: same order and arithmetic as trace_ray
         int hit = -1; float best = tmax;
         const V3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
         const int nw = g.numWalls;
         const WallZ wz = ray_wall_z(o.z, d.z, inv.z);          // the z slab is the same for every wall
-        for (int q = 0; q < nw; ++q) {
-            float t = ray_wall_xy(o.x - g.wall[q][0], o.y - g.wall[q][1], d, inv, g.wall[q][2], g.wall[q][3], wz);
-            if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + q; }
+        // (a ray with an exactly zero x or y component takes the general form; decided per wave)
+        if (__ballot(d.x == 0.f || d.y == 0.f) == 0) {
+            WallScan ws(tmax, wz);                              // (t_max is 200 or 1: positive, so +1 ulp is the next float up)
+            for (int q = 0; q < nw; ++q)
+                ws.wall(o.x - g.wall[q][0], o.y - g.wall[q][1], inv, g.wall[q][2], g.wall[q][3], kHitWallBase + q);
+            ws.finish(tmax);
+            best = ws.best; hit = ws.hit;
+        } else {
+            for (int q = 0; q < nw; ++q) {
+                float t = ray_wall_xy(o.x - g.wall[q][0], o.y - g.wall[q][1], d, inv, g.wall[q][2], g.wall[q][3], wz);
+                if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitWallBase + q; }
+            }
         }
+        HS_OTICK(3)
         const int np = g.numPlanes;
         for (int p = 0; p < np; ++p) {
             V3 n = {g.plane[p][0], g.plane[p][1], g.plane[p][2]};
@@ -179,6 +209,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             float t = -dist / dn;
             if (t >= 0.f && t <= best && (hit < 0 || t < best)) { best = t; hit = kHitPlaneBase + p; }
         }
+        HS_OTICK(4)
         unsigned long long key = hit < 0 ? ray_key(tmax, kKeyMiss) : ray_key(best, hit);
         // movable hulls: conservative cull here, exact test in pass 2
         const float dd2 = dot(d, d);
@@ -186,8 +217,8 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             const int m = g.meta[b];
             if (m == 0) continue;
             const int obj = meta_obj(m);
-            const V3 mo = o - geom_pos(g, b);
-            const float bb = dot(mo, d), cc = dot(mo, mo) - obj_bound_r2(obj);
+            const V3 mo = {sh.rel[i][b][0], sh.rel[i][b][1], sh.rel[i][b][2]};
+            const float bb = dot(mo, d), cc = sh.rel[i][b][3];
             if (cc > 0.f && (bb > 0.f || bb * bb < dd2 * cc * 0.999f)) continue;
             const int slotp = atomicAdd(&sh.nPairs, 1);
             if (slotp < kMaxPairs) {
@@ -203,6 +234,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         sh.rayKey[r] = key;
     }
     __syncthreads();
+    HS_OTICK(5)
     // ---------------- pass 2: exact ray-vs-hull tests, one thread per surviving pair ----------------
     {
         const int np2 = sh.nPairs < kMaxPairs ? sh.nPairs : kMaxPairs;
@@ -215,11 +247,16 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             const float tmax = (r % kRaysPerAgent) < 30 ? 200.f : 1.f;
             Q qi = qinv(geom_rot(g, b));
             V3 ol = qrot(qi, o - geom_pos(g, b)), dl = qrot(qi, d);
-            float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
+            float t;
+            if (__ballot(obj != OBJ_RAMP && (dl.x == 0.f || dl.y == 0.f || dl.z == 0.f)) == 0)
+                t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local_nz(ol, dl, obj_half_extents(obj));
+            else
+                t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
             if (t >= 0.f && t <= tmax) atomicMin(&sh.rayKey[r], ray_key(t, b));
         }
     }
     __syncthreads();
+    HS_OTICK(6)
     // ---------------- pass 3: ray results -> exported columns ----------------
     for (int r = tid; r < nRays; r += NT) {
         const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
@@ -248,6 +285,7 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             }
         }
     }
+    HS_OTICK(7)
     // ---------------- collectObservationsSystem rows + globalPositionsDebugSystem ----------------
     const int nObs = A * 17;
     for (int item = tid; item < nObs + 1; item += NT) {
@@ -330,6 +368,8 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             for (; o < kMaxAgents; o += 2) { ga[o * 2] = 0.f; ga[o * 2 + 1] = 0.f; }
         }
     }
+    HS_OTICK(8)
+#undef HS_OTICK
 }
 
 }  // namespace hs

@@ -115,6 +115,40 @@ HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, Wall
     return tn;
 }
 
+// The wall loop for rays with d.x != 0 and d.y != 0 (decided once per wave), fused with trace_ray's "closest hit, ties
+// keep the lower id" update and free of branches.  Bit-identical to ray_wall_xy + that update for such rays:
+//  * the z slab's bounds lie within +-3.0e38, so they absorb the initial clamps of the x / y slabs (max / min ignore
+//    a NaN operand either way), and tn, tf are never NaN: the rejections can be written as positive comparisons;
+//  * "t <= best while nothing was hit, t < best afterwards" is "t < best" throughout when best starts one ulp above
+//    t_max (wall_best0; WallScan::finish puts t_max back when no wall was hit);
+//  * a ray whose z slab misses gets tn = 3.0e38, which is never below best.
+struct WallScan {
+    float best; int hit; float zn, zf;
+    HSD WallScan(float tmax, WallZ z) : best(__uint_as_float(__float_as_uint(tmax) + 1u)), hit(-1), zn(z.miss ? 3.0e38f : z.tn), zf(z.tf) {}
+    HSD void wall(float ox, float oy, V3 inv, float ex, float ey, int id) {
+        const float cx = (-ox) * inv.x, rx = ex * fabsf(inv.x);
+        const float cy = (-oy) * inv.y, ry = ey * fabsf(inv.y);
+        const float tn = fmaxf(fmaxf(cx - rx, cy - ry), zn);
+        const float tf = fminf(fminf(cx + rx, cy + ry), zf);
+        const bool ok = (tn <= tf) & (tn >= 0.f) & (tn < best);
+        best = ok ? tn : best;
+        hit = ok ? id : hit;
+    }
+    HSD void finish(float tmax) { if (hit < 0) best = tmax; }
+};
+
+// ray_box_local for a direction without zero components (decided once per wave).
+HSD float ray_box_local_nz(V3 o, V3 d, V3 e) {
+    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
+    const float cx = (-o.x) * ix, rx = e.x * fabsf(ix);
+    const float cy = (-o.y) * iy, ry = e.y * fabsf(iy);
+    const float cz = (-o.z) * iz, rz = e.z * fabsf(iz);
+    const float tn = fmaxf(fmaxf(fmaxf(-3.0e38f, cx - rx), cy - ry), cz - rz);
+    const float tf = fminf(fminf(fminf(3.0e38f, cx + rx), cy + ry), cz + rz);
+    if (tn > tf || tn < 0.f) return -1.f;
+    return tn;
+}
+
 // Squared bounding-sphere radius of a movable hull about its origin, inflated by 2% so that the
 // conservative pre-test below can never reject a ray the exact test would accept.
 HSD float obj_bound_r2(int obj) {

@@ -28,3 +28,16 @@ for i, nm in enumerate(names):
     print(f"{nm:10s} {us[:, i].mean():7.1f} {us[:, i].min():7.1f} {us[:, i].max():7.1f}")
 tot = us.sum(axis=1)
 print(f"total      {tot.mean():7.1f} {tot.min():7.1f} {tot.max():7.1f}")
+
+# k_observe sections (ticks summed over all waves; 3 waves per world at 4 agents; sections inside the ray loop are
+# reported by the waves whose first lane has a ray)
+ob = np.zeros(16, np.int64)
+L.hs_debug_observe_ticks.argtypes = [C.c_void_p, C.c_void_p]
+if L.hs_debug_observe_ticks(sim._h, ob.ctypes.data) == 0:
+    launches = steps + 1
+    waves = N * ((4 * 46 + 63) // 64)
+    onames = ["stage(+wait)", "agent table", "ray setup", "walls", "planes", "cull(+barrier)", "hull tests", "ray results", "obs rows"]
+    tot = ob[:9].sum()
+    print("k_observe section    us per wave per launch   share")
+    for i, nm in enumerate(onames):
+        print(f"{nm:18s} {ob[i] / 100.0 / launches / waves:10.2f} {100.0 * ob[i] / max(tot, 1):8.1f} %")
