@@ -121,9 +121,11 @@ HSD float hs_atanf(float xin) {
     float sign = xin < 0.f ? -1.f : 1.f;
     float x = fabsf(xin);
     float y;
-    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.f / x); }
-    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.f) / (x + 1.f); }
-    else { y = 0.f; }
+    // ranges: x > tan(3pi/8): pi/2 + atan(-(1/x));  x > tan(pi/8): pi/4 + atan((x-1)/(x+1));  else atan(x).  One division
+    // serves both reductions: (-1)/x is the same correctly rounded quotient as -(1/x).
+    const bool big = x > 2.414213562373095f, mid = x > 0.4142135623730950f;
+    y = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.f);
+    if (mid) { const float num = big ? -1.f : x - 1.f, den = big ? x : x + 1.f; x = num / den; }
     float z = x * x;
     y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
     return sign * y;

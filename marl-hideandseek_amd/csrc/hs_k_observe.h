@@ -25,10 +25,20 @@
 
 namespace hs {
 
+// Timing probes (development aid, results are wrong when set): -DHS_OBS_SKIP=<bits> leaves sections of k_observe out:
+// 1 walls, 2 hull cull (no pairs), 4 exact hull tests, 8 observation rows, 16 ray results, 32 everything after staging.
+#ifndef HS_OBS_SKIP
+#define HS_OBS_SKIP 0
+#endif
+
+// waves per SIMD the register allocation of k_observe aims at
+#ifndef HS_OBS_WAVES
+#define HS_OBS_WAVES 8
+#endif
+
 constexpr int kRaysPerAgent = 46;                          // 30 lidar + 16 visibility targets
 // NT threads = one lane per ray of A agents, rounded up to whole waves: the per-ray / per-agent LDS is sized by NT
 constexpr int obs_max_agents(int nt) { return nt / kRaysPerAgent < kMaxAgents ? nt / kRaysPerAgent : kMaxAgents; }
-constexpr int kMaxPairs = 1536;
 
 template <int NT>
 struct ObsShared {
@@ -37,13 +47,20 @@ struct ObsShared {
     float lin[kNumDSlots][3];
     float ang[kNumDSlots][3];
     int grab[kMaxAgents];
-    float rayO[kMaxRays][3], rayD[kMaxRays][3];
+    float rayD[kMaxRays][3];
     unsigned long long rayKey[kMaxRays];
-    unsigned short pairs[kMaxPairs];                       // ray << 5 | body slot
-    int nPairs;
+    // (ray, hull) pairs that survive the bounding-sphere cull, ray << 5 | body slot: every wave of pass 1 fills its own
+    // region, sized for all its rays against every other box-shaped hull (9 boxes + 5 agents) / every ramp
+    static constexpr int kWaves = NT / 64, kWavePairs = 64 * (kMaxBoxes + kMaxAgents - 1), kWaveRampPairs = 64 * kMaxRamps;
+    unsigned short pairs[kWaves][kWavePairs];
+    unsigned short rampPairs[kWaves][kWaveRampPairs];
+    int nPairs[kWaves], nRampPairs[kWaves];
+    unsigned present;                                      // bit b: body slot b exists
     float lidarSin[30], lidarCos[30];                      // hs_sincosf of the 30 lidar angles, once per workgroup
-    // per (agent, body slot): origin - body position and |.|^2 - bounding radius^2, shared by the agent's 46 rays
-    float rel[kAgents][kNumDSlots][4];
+    // per (agent, body slot), shared by the agent's 46 rays: origin - body position, |.|^2 - bounding radius^2, and
+    // the origin in the body's frame
+    alignas(16) float rel[kAgents][kNumDSlots][8];
+    float fwd[kAgents][3], right[kAgents][3];              // the agents' forward / right axes
 };
 
 HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
@@ -65,17 +82,12 @@ HSD void stage_world(const SimState &S, int w, int ps, ObsShared<NT> &sh, int ti
         int c = i / kNumDSlots, s = i % kNumDSlots;
         sh.g.rot[s][c] = S.brot(c * kNumDSlots + s, ps);
     }
-    const int nw = S.numWalls[w], np = S.numPlanes[w];
-    if (tid == 0) { sh.g.numWalls = nw; sh.g.numPlanes = np; sh.nPairs = 0; }
-    for (int i = tid; i < nw * 4; i += NT) {
-        int c = i / nw, k = i % nw;
-        sh.g.wall[k][c] = S.walls(c * kMaxWalls + k, ps);
-    }
-    for (int i = tid; i < np * 4; i += NT) {
-        int c = i / np, p = i % np;
-        sh.g.plane[p][c] = S.planes(c * kMaxPlanes + p, ps);
-    }
+    // (all 36 wall rows and 3 plane rows are fetched whatever the counts are: no load waits for another one)
+    for (int i = tid; i < 4 * kMaxWalls; i += NT) sh.g.wall[i % kMaxWalls][i / kMaxWalls] = S.walls(i, ps);
+    for (int i = tid; i < 4 * kMaxPlanes; i += NT) sh.g.plane[i % kMaxPlanes][i / kMaxPlanes] = S.planes(i, ps);
+    if (tid == 0) { sh.g.numWalls = S.numWalls[w]; sh.g.numPlanes = S.numPlanes[w]; sh.present = 0; }
     for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther(i, ps);
+    if (tid < NT / 64) { sh.nPairs[tid] = 0; sh.nRampPairs[tid] = 0; }
 }
 
 HSD unsigned long long ray_key(float t, int id) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id; }
@@ -84,7 +96,7 @@ constexpr unsigned kKeyMiss = 0xffffffffu;
 // NT = threads per world = A*46 rays rounded up to whole waves (192 for the 4-agent benchmark): every
 // lane of pass 1 / pass 3 has a ray.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_observe(SimState S) {
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_WAVES, HS_OBS_WAVES))) k_observe(SimState S) {
     __shared__ ObsShared<NT> sh;
     const int tid = threadIdx.x;
 #ifdef HS_PHASE_TIMING
@@ -138,13 +150,25 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     const WorldGeom &g = sh.g;
     const int nAgents = cnt_agents(counts), nBoxes = cnt_boxes(counts), nRamps = cnt_ramps(counts);
     const int nRays = A * kRaysPerAgent;
+    if (HS_OBS_SKIP & 32) return;
     HS_OTICK(0)
     for (int item = tid; item < nAgents * kNumDSlots; item += NT) {
         const int i = item / kNumDSlots, b = item % kNumDSlots;
-        const V3 mo = geom_pos(g, kAgentSlot0 + i) - geom_pos(g, b);
         const int m = g.meta[b];
-        sh.rel[i][b][0] = mo.x; sh.rel[i][b][1] = mo.y; sh.rel[i][b][2] = mo.z;
-        sh.rel[i][b][3] = dot(mo, mo) - obj_bound_r2(meta_obj(m));
+        if (m == 0) continue;
+        if (i == 0) atomicOr(&sh.present, 1u << b);
+        const V3 mo = geom_pos(g, kAgentSlot0 + i) - geom_pos(g, b);
+        const V3 ol = qrot(qinv(geom_rot(g, b)), mo);
+        float *e = sh.rel[i][b];
+        e[0] = mo.x; e[1] = mo.y; e[2] = mo.z;
+        e[3] = dot(mo, mo) - obj_bound_r2(meta_obj(m));
+        e[4] = ol.x; e[5] = ol.y; e[6] = ol.z;
+    }
+    for (int i = tid - (NT - 8); i >= 0 && i < nAgents; i += NT) {          // (the last lanes: they have no table item)
+        const Q rot = geom_rot(g, kAgentSlot0 + i);
+        const V3 f = qrot(rot, {0.f, 1.f, 0.f}), rt = qrot(rot, {1.f, 0.f, 0.f});
+        sh.fwd[i][0] = f.x; sh.fwd[i][1] = f.y; sh.fwd[i][2] = f.z;
+        sh.right[i][0] = rt.x; sh.right[i][1] = rt.y; sh.right[i][2] = rt.z;
     }
     __syncthreads();
     HS_OTICK(1)
@@ -155,13 +179,12 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         sh.rayKey[r] = ray_key(-1.f, kKeyMiss);               // "no ray" (visibility ray not cast)
         if (i >= nAgents) continue;
         const int slot = kAgentSlot0 + i;
-        const Q rot = geom_rot(g, slot);
         const V3 o = geom_pos(g, slot);
-        const V3 fwd = qrot(rot, {0.f, 1.f, 0.f});
+        const V3 fwd = {sh.fwd[i][0], sh.fwd[i][1], sh.fwd[i][2]};
         V3 d; float tmax;
         if (k < 30) {
             // lidarSystem: 30 rays in the agent's horizontal plane, t_max 200 (sim.cpp:727-738)
-            const V3 right = qrot(rot, {1.f, 0.f, 0.f});
+            const V3 right = {sh.right[i][0], sh.right[i][1], sh.right[i][2]};
             const float s = sh.lidarSin[k], c = sh.lidarCos[k];
             d = normalize(right * c + fwd * s);
             tmax = 200.f;
@@ -177,19 +200,20 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
             if (dot(normalize(d), fwd) < kCosFovHalf) continue;
             tmax = 1.f;
         }
-        sh.rayO[r][0] = o.x; sh.rayO[r][1] = o.y; sh.rayO[r][2] = o.z;
         sh.rayD[r][0] = d.x; sh.rayD[r][1] = d.y; sh.rayD[r][2] = d.z;
         HS_OTICK(2)
         // static geometry: same order and arithmetic as trace_ray
         int hit = -1; float best = tmax;
         const V3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
-        const int nw = g.numWalls;
+        const int nw = (HS_OBS_SKIP & 1) ? 0 : g.numWalls;
         const WallZ wz = ray_wall_z(o.z, d.z, inv.z);          // the z slab is the same for every wall
         // (a ray with an exactly zero x or y component takes the general form; decided per wave)
         if (__ballot(d.x == 0.f || d.y == 0.f) == 0) {
-            WallScan ws(tmax, wz);                              // (t_max is 200 or 1: positive, so +1 ulp is the next float up)
-            for (int q = 0; q < nw; ++q)
-                ws.wall(o.x - g.wall[q][0], o.y - g.wall[q][1], inv, g.wall[q][2], g.wall[q][3], kHitWallBase + q);
+            WallScan ws(tmax, wz, o.x, o.y, inv);              // (t_max is 200 or 1: positive, so +1 ulp is the next float up)
+            for (int q = 0; q < nw; ++q) {
+                const f32x2 *wq = reinterpret_cast<const f32x2 *>(g.wall[q]);
+                ws.wall(wq[0], wq[1], kHitWallBase + q);
+            }
             ws.finish(tmax);
             best = ws.best; hit = ws.hit;
         } else {
@@ -211,54 +235,85 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
         }
         HS_OTICK(4)
         unsigned long long key = hit < 0 ? ray_key(tmax, kKeyMiss) : ray_key(best, hit);
-        // movable hulls: conservative cull here, exact test in pass 2
+        // movable hulls: conservative bounding-sphere cull here, exact test in pass 2.  The loop over the bodies is
+        // uniform, so the survivors of one body are a lane mask (ballot) and their pairs go to consecutive entries of
+        // this wave's region of the pair list: no atomics.  The agent's own hull is left out: its centre is the ray's
+        // origin (origin - centre is exactly 0), and a ray that starts inside a hull never hits it (every slab's entry
+        // is negative).
         const float dd2 = dot(d, d);
+        const unsigned others = __builtin_amdgcn_readfirstlane(sh.present) & ((HS_OBS_SKIP & 2) ? 0u : ~0u);
+        const float *relI = &sh.rel[i][0][0];
+        constexpr unsigned kRampBits = ((1u << kMaxRamps) - 1u) << kRampSlot0;
+        const int wv = tid >> 6;
+        int at = 0, ar = 0;                                     // (uniform: entries of this wave's regions in use)
+#pragma unroll
         for (int b = 0; b < kNumDSlots; ++b) {
-            const int m = g.meta[b];
+            if (!((others >> b) & 1u)) continue;
+            const float4 e = *reinterpret_cast<const float4 *>(relI + b * 8);
+            const float bb = e.x * d.x + e.y * d.y + e.z * d.z, cc = e.w;
+            // culled: cc > 0 && (bb > 0 || bb * bb < dd2 * cc * 0.999f) — as lane masks (ordered comparisons 2 = ">",
+            // 4 = "<"; 32 = integer "=="), combined by scalar instructions
+            unsigned long long m = __builtin_amdgcn_fcmpf(cc, 0.f, 2) &
+                                   (__builtin_amdgcn_fcmpf(bb, 0.f, 2) | __builtin_amdgcn_fcmpf(bb * bb, dd2 * cc * 0.999f, 4));
+            if (b >= kAgentSlot0) m |= __builtin_amdgcn_sicmp(slot, b, 32);
+            m = __builtin_amdgcn_read_exec() & ~m;             // the rays that keep body b
             if (m == 0) continue;
-            const int obj = meta_obj(m);
-            const V3 mo = {sh.rel[i][b][0], sh.rel[i][b][1], sh.rel[i][b][2]};
-            const float bb = dot(mo, d), cc = sh.rel[i][b][3];
-            if (cc > 0.f && (bb > 0.f || bb * bb < dd2 * cc * 0.999f)) continue;
-            const int slotp = atomicAdd(&sh.nPairs, 1);
-            if (slotp < kMaxPairs) {
-                sh.pairs[slotp] = (unsigned short)((r << 5) | b);
-            } else {
-                // pair list full: test in place
-                Q qi = qinv(geom_rot(g, b));
-                V3 ol = qrot(qi, mo), dl = qrot(qi, d);
-                float t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
-                if (t >= 0.f && t <= tmax) { unsigned long long kk = ray_key(t, b); key = kk < key ? kk : key; }
+            const bool ramp = (kRampBits >> b) & 1u;
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                const int idx = (ramp ? ar : at) + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                (ramp ? sh.rampPairs[wv] : sh.pairs[wv])[idx] = (unsigned short)((r << 5) | b);
             }
+            if (ramp) ar += __builtin_popcountll(m); else at += __builtin_popcountll(m);
         }
+        if ((tid & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) { sh.nPairs[wv] = at; sh.nRampPairs[wv] = ar; }
         sh.rayKey[r] = key;
     }
     __syncthreads();
     HS_OTICK(5)
+#ifdef HS_PHASE_TIMING
+    if (tid < NT / 64) { atomicAdd((unsigned long long *)&oacc[9], (unsigned long long)sh.nPairs[tid]); atomicAdd((unsigned long long *)&oacc[10], (unsigned long long)sh.nRampPairs[tid]); }
+#endif
     // ---------------- pass 2: exact ray-vs-hull tests, one thread per surviving pair ----------------
+    // (box-shaped hulls and ramps from separate lists: a wave runs one kind of test)
     {
-        const int np2 = sh.nPairs < kMaxPairs ? sh.nPairs : kMaxPairs;
+        constexpr int NW = NT / 64;
+        int np2 = 0, nr2 = 0;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) { np2 += sh.nPairs[v]; nr2 += sh.nRampPairs[v]; }
+        if (HS_OBS_SKIP & 4) { np2 = 0; nr2 = 0; }
         for (int p = tid; p < np2; p += NT) {
-            const int pr = sh.pairs[p];
+            int q = p, v = 0;                                     // p-th pair of the concatenated regions
+#pragma unroll
+            for (int u = 0; u < NW - 1; ++u) { const int n = sh.nPairs[u]; if (v == u && q >= n) { q -= n; v = u + 1; } }
+            const int pr = sh.pairs[v][q];
             const int r = pr >> 5, b = pr & 31;
-            const int obj = meta_obj(g.meta[b]);
-            const V3 o = {sh.rayO[r][0], sh.rayO[r][1], sh.rayO[r][2]};
-            const V3 d = {sh.rayD[r][0], sh.rayD[r][1], sh.rayD[r][2]};
-            const float tmax = (r % kRaysPerAgent) < 30 ? 200.f : 1.f;
-            Q qi = qinv(geom_rot(g, b));
-            V3 ol = qrot(qi, o - geom_pos(g, b)), dl = qrot(qi, d);
-            float t;
-            if (__ballot(obj != OBJ_RAMP && (dl.x == 0.f || dl.y == 0.f || dl.z == 0.f)) == 0)
-                t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local_nz(ol, dl, obj_half_extents(obj));
-            else
-                t = obj == OBJ_RAMP ? ray_wedge_local(ol, dl) : ray_box_local(ol, dl, obj_half_extents(obj));
+            const int i = r / kRaysPerAgent;
+            const float *e = sh.rel[i][b];
+            const V3 ol = {e[4], e[5], e[6]};
+            const V3 dl = qrot(qinv(geom_rot(g, b)), {sh.rayD[r][0], sh.rayD[r][1], sh.rayD[r][2]});
+            const V3 he = obj_half_extents(meta_obj(g.meta[b]));
+            const float tmax = (r - i * kRaysPerAgent) < 30 ? 200.f : 1.f;
+            const float t = __ballot(dl.x == 0.f || dl.y == 0.f || dl.z == 0.f) == 0 ? ray_box_local_nz(ol, dl, he) : ray_box_local(ol, dl, he);
+            if (t >= 0.f && t <= tmax) atomicMin(&sh.rayKey[r], ray_key(t, b));
+        }
+        for (int p = NT - 1 - tid; p < nr2; p += NT) {                // (the last wave first: it has the fewest box pairs)
+            int q = p, v = 0;
+#pragma unroll
+            for (int u = 0; u < NW - 1; ++u) { const int n = sh.nRampPairs[u]; if (v == u && q >= n) { q -= n; v = u + 1; } }
+            const int pr = sh.rampPairs[v][q];
+            const int r = pr >> 5, b = pr & 31;
+            const int i = r / kRaysPerAgent;
+            const float *e = sh.rel[i][b];
+            const V3 dl = qrot(qinv(geom_rot(g, b)), {sh.rayD[r][0], sh.rayD[r][1], sh.rayD[r][2]});
+            const float tmax = (r - i * kRaysPerAgent) < 30 ? 200.f : 1.f;
+            const float t = ray_wedge_local({e[4], e[5], e[6]}, dl);
             if (t >= 0.f && t <= tmax) atomicMin(&sh.rayKey[r], ray_key(t, b));
         }
     }
     __syncthreads();
     HS_OTICK(6)
     // ---------------- pass 3: ray results -> exported columns ----------------
-    for (int r = tid; r < nRays; r += NT) {
+    for (int r = tid; r < ((HS_OBS_SKIP & 16) ? 0 : nRays); r += NT) {
         const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
         if (i >= nAgents) continue;
         const int row = w * A + i;
@@ -287,10 +342,12 @@ __global__ void __launch_bounds__(NT) k_observe(SimState S) {
     }
     HS_OTICK(7)
     // ---------------- collectObservationsSystem rows + globalPositionsDebugSystem ----------------
-    const int nObs = A * 17;
+    // items: A*16 (agent, other entity) rows first — a whole wave of the same work for 4 agents —, then the A self rows,
+    // then the debug positions
+    const int nRel = A * 16, nObs = (HS_OBS_SKIP & 8) ? -1 : nRel + A;
     for (int item = tid; item < nObs + 1; item += NT) {
         if (item < nObs) {
-            const int i = item / 17, e = item % 17;
+            const int i = item < nRel ? item >> 4 : item - nRel, e = item < nRel ? 1 + (item & 15) : 0;
             if (i >= nAgents) continue;
             const int row = w * A + i;
             const int slot = kAgentSlot0 + i;

@@ -122,14 +122,22 @@ HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, Wall
 //  * "t <= best while nothing was hit, t < best afterwards" is "t < best" throughout when best starts one ulp above
 //    t_max (wall_best0; WallScan::finish puts t_max back when no wall was hit);
 //  * a ray whose z slab misses gets tn = 3.0e38, which is never below best.
+//  The x and y slabs are evaluated as one two-component vector (gfx950 has packed f32 multiply / add: each component is
+//  the same IEEE operation as the scalar form).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct WallScan {
     float best; int hit; float zn, zf;
-    HSD WallScan(float tmax, WallZ z) : best(__uint_as_float(__float_as_uint(tmax) + 1u)), hit(-1), zn(z.miss ? 3.0e38f : z.tn), zf(z.tf) {}
-    HSD void wall(float ox, float oy, V3 inv, float ex, float ey, int id) {
-        const float cx = (-ox) * inv.x, rx = ex * fabsf(inv.x);
-        const float cy = (-oy) * inv.y, ry = ey * fabsf(inv.y);
-        const float tn = fmaxf(fmaxf(cx - rx, cy - ry), zn);
-        const float tf = fminf(fminf(cx + rx, cy + ry), zf);
+    f32x2 o, inv, ainv;
+    HSD WallScan(float tmax, WallZ z, float ox, float oy, V3 iv)
+        : best(__uint_as_float(__float_as_uint(tmax) + 1u)), hit(-1), zn(z.miss ? 3.0e38f : z.tn), zf(z.tf) {
+        o = {ox, oy}; inv = {iv.x, iv.y}; ainv = {fabsf(iv.x), fabsf(iv.y)};
+    }
+    // wall = (cx, cy, hx, hy)
+    HSD void wall(f32x2 centre, f32x2 half, int id) {
+        const f32x2 c = (-(o - centre)) * inv, r = half * ainv;
+        const f32x2 lo = c - r, hi = c + r;
+        const float tn = fmaxf(fmaxf(lo.x, lo.y), zn);
+        const float tf = fminf(fminf(hi.x, hi.y), zf);
         const bool ok = (tn <= tf) & (tn >= 0.f) & (tn < best);
         best = ok ? tn : best;
         hit = ok ? id : hit;

@@ -41,3 +41,4 @@ if L.hs_debug_observe_ticks(sim._h, ob.ctypes.data) == 0:
     print("k_observe section    us per wave per launch   share")
     for i, nm in enumerate(onames):
         print(f"{nm:18s} {ob[i] / 100.0 / launches / waves:10.2f} {100.0 * ob[i] / max(tot, 1):8.1f} %")
+    print(f"pairs per world per launch: {ob[9] / launches / N:.1f} box-shaped, {ob[10] / launches / N:.1f} ramps")
