@@ -88,11 +88,9 @@ void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
     if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
     // one workgroup per world; the grid covers whole groups of 8 octets (k_observe's block -> world mapping)
     const int N = ((S.N + hs::kTile - 1) / hs::kTile + 7) / 8 * 64;
-    const int nt = (s->A * hs::kRaysPerAgent + 63) / 64 * 64;      // one lane per ray, whole waves
-    if (nt <= 64) hipLaunchKernelGGL(hs::k_observe<64>, dim3(N), dim3(64), 0, strm, S);
-    else if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);
+    const int nt = hs::obs_threads(s->A);                          // a lane per ray (hs_k_observe.h)
+    if (nt <= 128) hipLaunchKernelGGL(hs::k_observe<128>, dim3(N), dim3(128), 0, strm, S);
     else if (nt <= 192) hipLaunchKernelGGL(hs::k_observe<192>, dim3(N), dim3(192), 0, strm, S);
-    else if (nt <= 256) hipLaunchKernelGGL(hs::k_observe<256>, dim3(N), dim3(256), 0, strm, S);
     else hipLaunchKernelGGL(hs::k_observe<320>, dim3(N), dim3(320), 0, strm, S);
 }
 

@@ -37,8 +37,17 @@ namespace hs {
 #endif
 
 constexpr int kRaysPerAgent = 46;                          // 30 lidar + 16 visibility targets
-// NT threads = one lane per ray of A agents, rounded up to whole waves: the per-ray / per-agent LDS is sized by NT
-constexpr int obs_max_agents(int nt) { return nt / kRaysPerAgent < kMaxAgents ? nt / kRaysPerAgent : kMaxAgents; }
+// Lane layout of the rays: the A*30 lidar rays first (ray = agent * 30 + k), the A*16 visibility rays from the next
+// wave boundary on (ray = base + agent * 16 + target): a wave runs one kind of ray set-up.
+constexpr int obs_vis_base(int a) { return (a * 30 + 63) / 64 * 64; }
+constexpr int obs_threads(int a) { return (obs_vis_base(a) + a * 16 + 63) / 64 * 64; }       // 128, 128, 192, 192, 320, 320
+constexpr int obs_max_agents(int nt) { int a = 1; while (a < kMaxAgents && obs_threads(a + 1) <= nt) ++a; return a; }
+struct RayId { int agent, k; };                            // k < 30: lidar ray k; else visibility target k - 30
+HSD RayId ray_id(int r, int visBase) {
+    if (r < visBase) { const int i = r / 30; return {i, r - i * 30}; }
+    const int rr = r - visBase;
+    return {rr >> 4, 30 + (rr & 15)};
+}
 
 template <int NT>
 struct ObsShared {
@@ -93,8 +102,7 @@ HSD void stage_world(const SimState &S, int w, int ps, ObsShared<NT> &sh, int ti
 HSD unsigned long long ray_key(float t, int id) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id; }
 constexpr unsigned kKeyMiss = 0xffffffffu;
 
-// NT = threads per world = A*46 rays rounded up to whole waves (192 for the 4-agent benchmark): every
-// lane of pass 1 / pass 3 has a ray.
+// NT = threads per world = obs_threads(A) (192 for the 4-agent benchmark): a lane per ray.
 template <int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_WAVES, HS_OBS_WAVES))) k_observe(SimState S) {
     __shared__ ObsShared<NT> sh;
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
     __syncthreads();
     const WorldGeom &g = sh.g;
     const int nAgents = cnt_agents(counts), nBoxes = cnt_boxes(counts), nRamps = cnt_ramps(counts);
-    const int nRays = A * kRaysPerAgent;
+    const int visBase = obs_vis_base(A);
     if (HS_OBS_SKIP & 32) return;
     HS_OTICK(0)
     for (int item = tid; item < nAgents * kNumDSlots; item += NT) {
@@ -174,10 +182,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
     HS_OTICK(1)
 
     // ---------------- pass 1: ray setup, walls + planes, cull against the movable hulls ----------------
-    for (int r = tid; r < nRays; r += NT) {
-        const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
+    for (int r = tid; r < NT; r += NT) {                       // (one trip: a lane per ray)
+        const RayId id = ray_id(r, visBase);
+        const int i = id.agent, k = id.k;
         sh.rayKey[r] = ray_key(-1.f, kKeyMiss);               // "no ray" (visibility ray not cast)
-        if (i >= nAgents) continue;
+        if (i >= nAgents) continue;                            // (also the padding lanes between the two kinds)
         const int slot = kAgentSlot0 + i;
         const V3 o = geom_pos(g, slot);
         const V3 fwd = {sh.fwd[i][0], sh.fwd[i][1], sh.fwd[i][2]};
@@ -287,12 +296,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
             for (int u = 0; u < NW - 1; ++u) { const int n = sh.nPairs[u]; if (v == u && q >= n) { q -= n; v = u + 1; } }
             const int pr = sh.pairs[v][q];
             const int r = pr >> 5, b = pr & 31;
-            const int i = r / kRaysPerAgent;
+            const int i = ray_id(r, visBase).agent;
             const float *e = sh.rel[i][b];
             const V3 ol = {e[4], e[5], e[6]};
             const V3 dl = qrot(qinv(geom_rot(g, b)), {sh.rayD[r][0], sh.rayD[r][1], sh.rayD[r][2]});
             const V3 he = obj_half_extents(meta_obj(g.meta[b]));
-            const float tmax = (r - i * kRaysPerAgent) < 30 ? 200.f : 1.f;
+            const float tmax = r < visBase ? 200.f : 1.f;
             const float t = __ballot(dl.x == 0.f || dl.y == 0.f || dl.z == 0.f) == 0 ? ray_box_local_nz(ol, dl, he) : ray_box_local(ol, dl, he);
             if (t >= 0.f && t <= tmax) atomicMin(&sh.rayKey[r], ray_key(t, b));
         }
@@ -302,10 +311,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
             for (int u = 0; u < NW - 1; ++u) { const int n = sh.nRampPairs[u]; if (v == u && q >= n) { q -= n; v = u + 1; } }
             const int pr = sh.rampPairs[v][q];
             const int r = pr >> 5, b = pr & 31;
-            const int i = r / kRaysPerAgent;
+            const int i = ray_id(r, visBase).agent;
             const float *e = sh.rel[i][b];
             const V3 dl = qrot(qinv(geom_rot(g, b)), {sh.rayD[r][0], sh.rayD[r][1], sh.rayD[r][2]});
-            const float tmax = (r - i * kRaysPerAgent) < 30 ? 200.f : 1.f;
+            const float tmax = r < visBase ? 200.f : 1.f;
             const float t = ray_wedge_local({e[4], e[5], e[6]}, dl);
             if (t >= 0.f && t <= tmax) atomicMin(&sh.rayKey[r], ray_key(t, b));
         }
@@ -313,8 +322,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
     __syncthreads();
     HS_OTICK(6)
     // ---------------- pass 3: ray results -> exported columns ----------------
-    for (int r = tid; r < ((HS_OBS_SKIP & 16) ? 0 : nRays); r += NT) {
-        const int i = r / kRaysPerAgent, k = r % kRaysPerAgent;
+    for (int r = tid; r < ((HS_OBS_SKIP & 16) ? 0 : NT); r += NT) {
+        const RayId rid = ray_id(r, visBase);
+        const int i = rid.agent, k = rid.k;
         if (i >= nAgents) continue;
         const int row = w * A + i;
         const unsigned long long key = sh.rayKey[r];
