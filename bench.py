@@ -150,7 +150,7 @@ def main():
     dt = time.perf_counter() - t0
     obs_pass_steps = 0
     if overlapped:
-        # Under the dependency schedule (the default) k_observe runs beside k_physics and has no duration of its own in
+        # Under the dependency schedule (HS_OVERLAP=1) k_observe runs beside k_physics and has no duration of its own in
         # the timed region; its kernel time comes from an extra, untimed pass with the two kernels launched one after
         # the other (same results).  k_physics' events above are from the timed region.
         sim.set_overlap(False)

@@ -217,8 +217,9 @@ typedef struct hs_device_status {
 } hs_device_status;
 int32_t hs_get_device_status(hs_sim *sim, hs_device_status *out);
 /* The dependency schedule between the two kernels of a step (k_observe beside k_physics, taking octets of worlds in
- * the order physics finishes them) is on by default when the whole batch is resident on the device (<= 64 worlds per
- * CU); 0 launches the kernels one after the other (what HS_OVERLAP=0 does for every handle).  Results are identical. */
+ * the order physics finishes them) is opt-in (1 here, or HS_OVERLAP=1 for every handle) and takes effect when the
+ * whole batch is resident on the device (<= 64 worlds per CU); by default the kernels are launched one after the other.
+ * Results are identical. */
 int32_t hs_set_overlap(hs_sim *sim, int32_t enabled);
 /* Test hook: plants `code` in the device-side sched_error word as an expired wait would. */
 int32_t hs_debug_inject_sched_error(hs_sim *sim, int32_t code);

@@ -43,11 +43,16 @@ struct hs_sim {
     bool initialised = false;
     bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower than two direct launches)
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};     // physics, observe
-    // Dependency schedule (default on, HS_OVERLAP=0 or hs_set_overlap turn it off): k_observe is launched on its own
-    // stream beside k_physics and takes octets in the order their physics wave finishes.
-    bool overlap = true;
+    // Dependency schedule (opt-in: HS_OVERLAP=1 or hs_set_overlap): k_observe is launched on its own stream beside
+    // k_physics and takes octets in the order their physics wave finishes.  Off by default since k_observe takes under
+    // 0.1 ms: the agent-scope release every physics wave then needs (a write-back of its XCD's L2) and the slowdown of
+    // the physics waves that share a SIMD with k_observe cost more than the overlap hides.
+    bool overlap = false;
     bool overlapped_last = false;          // the last launch used obs_stream
     int slots = 0;                         // physics waves the device holds at once (8 per CU: LDS)
+    hipStream_t step_stream = nullptr;     // the stream of the open step
+    bool blocking_own_stream = false;      // HS_STREAM=own: hs_step uses the handle's stream as hs_step_begin does
+    int gate_pct = 0;                      // k_observe starts when this share of the physics waves has finished (HS_GATE_PCT)
     int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
     hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -130,7 +135,7 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
     if (overlap) {
-        hipLaunchKernelGGL(hs::k_gate, dim3(1), dim3(64), 0, s->obs_stream, S, noct);
+        hipLaunchKernelGGL(hs::k_gate, dim3(1), dim3(64), 0, s->obs_stream, S, noct, (int)((long long)noct * s->gate_pct / 100));
         launch_observe(s, s->obs_stream, s->sched_par);
         if (prof) HS_HIP(hipEventRecord(s->ev[3], s->obs_stream));
         if (!host_joins) {
@@ -313,6 +318,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
       HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
     S.stepPar = -1;
     HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N);
+    if ((rc = s->dalloc(&S.slotHdr, NP, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }      // world id -1: empty slot
+    HS_ALLOC(S.lidarSinCos, 60);
     HS_ALLOC(s->bal_hist, hs::kBalanceBins); HS_ALLOC(s->bal_cursor, hs::kBalanceBins); HS_ALLOC(s->bal_new_slot, N);
     { char *tmp; s->bal_tmp_bytes = (size_t)S.walls.kRows * NP * sizeof(float); HS_ALLOC(tmp, s->bal_tmp_bytes); s->bal_tmp = tmp; }
     HS_ALLOC(S.status, 4);
@@ -337,6 +344,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HS_OVERLAP")) s->overlap = atoi(e) != 0;
+    if (const char *e = getenv("HS_STREAM")) s->blocking_own_stream = std::strcmp(e, "own") == 0;
+    if (const char *e = getenv("HS_GATE_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) s->gate_pct = v; }
     if (const char *e = getenv("HS_BALANCE")) s->balance = atoi(e) != 0;
     if (const char *e = getenv("HS_BALANCE_PERIOD")) { const int v = atoi(e); if (v > 0) s->balance_period = v; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->gpu_id) == hipSuccess) s->slots = 8 * prop.multiProcessorCount; }
@@ -346,6 +355,8 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
         hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
     S.wbeg = 0; S.wcnt = (int)N;
+    hipLaunchKernelGGL(hs::k_lidar_table, dim3(1), dim3(64), 0, s->stream, S);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "k_lidar_table failed"); }
     std::memset(s->exports, 0, sizeof(s->exports));
     const int64_t n = (int64_t)N, r = (int64_t)R;
     set_desc(s, HS_EXPORT_RESET, S.xReset, HS_DTYPE_I32, {n, 1});
@@ -412,23 +423,33 @@ int32_t hs_init(hs_sim *s) {
     return HS_OK;
 }
 
-int32_t hs_step_begin(hs_sim *s) {
+namespace {
+// A blocking hs_step runs on the device's legacy default stream itself: it is ordered after the caller's writes to
+// `action` / `reset` there without a cross-stream event (which costs tens of microseconds per step), and the caller
+// waits for it anyway.  hs_step_begin / hs_step_end use the handle's own stream, so that the steps of several handles
+// (one per GPU) run side by side.
+int step_begin(hs_sim *s, bool own_stream) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     if (s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_step_begin: the previous step was not ended");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int rc = order_after_default_stream(s);
-    if (rc == HS_OK) rc = launch_step(s, s->stream, false, true);
+    int rc = HS_OK;
+    s->step_stream = own_stream ? s->stream : nullptr;
+    if (own_stream) rc = order_after_default_stream(s);
+    if (rc == HS_OK) rc = launch_step(s, s->step_stream, false, true);
     if (rc != HS_OK) return rc;
     s->step_open = true;
     return HS_OK;
 }
+}  // namespace
+
+int32_t hs_step_begin(hs_sim *s) { return step_begin(s, true); }
 
 int32_t hs_step_end(hs_sim *s) {
     if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
     if (!s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_step_end without hs_step_begin");
     s->step_open = false;
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    HS_HIP(hipStreamSynchronize(s->stream));
+    HS_HIP(hipStreamSynchronize(s->step_stream));
     if (s->overlapped_last) HS_HIP(hipStreamSynchronize(s->obs_stream));
     if (s->profiling) {
         HS_HIP(hipEventElapsedTime(&s->last_ms[0], s->ev[0], s->ev[1]));
@@ -441,7 +462,7 @@ int32_t hs_step_end(hs_sim *s) {
 }
 
 int32_t hs_step(hs_sim *s) {
-    int rc = hs_step_begin(s);
+    int rc = step_begin(s, s && s->blocking_own_stream);
     return rc != HS_OK ? rc : hs_step_end(s);
 }
 

@@ -10,6 +10,7 @@
 // stay where they are.  Worlds do not interact, so WHICH octet a world lives in changes no result — only the time.
 #pragma once
 #include "hs_state.h"
+#include "hs_k_reset.h"
 
 namespace hs {
 
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(256) k_balance_commit(SimState S, int nfull, c
     const int b = newSlot[w];
     S.slotOfWorld[w] = b;
     S.worldOfSlot[b] = w;
+    write_slot_hdr(S, w, b);
 }
 
 }  // namespace hs

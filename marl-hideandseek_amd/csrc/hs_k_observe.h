@@ -65,7 +65,6 @@ struct ObsShared {
     unsigned short rampPairs[kWaves][kWaveRampPairs];
     int nPairs[kWaves], nRampPairs[kWaves];
     unsigned present;                                      // bit b: body slot b exists
-    float lidarSin[30], lidarCos[30];                      // hs_sincosf of the 30 lidar angles, once per workgroup
     // per (agent, body slot), shared by the agent's 46 rays: origin - body position, |.|^2 - bounding radius^2, and
     // the origin in the body's frame
     alignas(16) float rel[kAgents][kNumDSlots][8];
@@ -79,7 +78,7 @@ HSD void store_posvel(float *o, V3 p, V3 e, V3 l, V3 a) {
 
 // Cooperative load of one world's geometry from the SoA columns into LDS.
 template <int NT>
-HSD void stage_world(const SimState &S, int w, int ps, ObsShared<NT> &sh, int tid) {
+HSD void stage_world(const SimState &S, int ps, ObsShared<NT> &sh, int tid) {
     for (int i = tid; i < kNumDSlots; i += NT) sh.g.meta[i] = S.bmeta(i, ps);
     for (int i = tid; i < kNumDSlots * 3; i += NT) {
         int c = i / kNumDSlots, s = i % kNumDSlots;
@@ -94,7 +93,6 @@ HSD void stage_world(const SimState &S, int w, int ps, ObsShared<NT> &sh, int ti
     // (all 36 wall rows and 3 plane rows are fetched whatever the counts are: no load waits for another one)
     for (int i = tid; i < 4 * kMaxWalls; i += NT) sh.g.wall[i % kMaxWalls][i / kMaxWalls] = S.walls(i, ps);
     for (int i = tid; i < 4 * kMaxPlanes; i += NT) sh.g.plane[i % kMaxPlanes][i / kMaxPlanes] = S.planes(i, ps);
-    if (tid == 0) { sh.g.numWalls = S.numWalls[w]; sh.g.numPlanes = S.numPlanes[w]; sh.present = 0; }
     for (int i = tid; i < kMaxAgents; i += NT) sh.grab[i] = S.grabOther(i, ps);
     if (tid < NT / 64) { sh.nPairs[tid] = 0; sh.nRampPairs[tid] = 0; }
 }
@@ -143,21 +141,25 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
         if (oct < 0) return;
     }
     const int p = oct * kTile + ((blk >> 3) & 7);       // slot in the tiled columns
-    const int w = S.worldOfSlot[p];                      // the world that lives there (exports, per-world scalars)
-    if (w < 0) return;
+    // the world that lives there and its scalars (exports are indexed by world id): one load, issued beside the
+    // column loads
+    const int4 hdr = S.slotHdr[p];
     const int A = S.A;
-    stage_world<NT>(S, w, p, sh, tid);
-    if (tid < 30) {       // lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent
-        float theta = 2.f * kPi * ((float)tid / 30.f) + kPi / 2.f;
-        hs_sincosf(theta, &sh.lidarSin[tid], &sh.lidarCos[tid]);
-    }
-    const int counts = S.counts[w];
-    const int teams = S.teams[w];
-    const int step = S.curEpisodeStep[w];
+    const int visBase = obs_vis_base(A);
+    // (this lane's lidar angle, fetched beside the column loads as well)
+    const RayId myRay = ray_id(tid, visBase);
+    float lidarS = 0.f, lidarC = 0.f;
+    if (tid < visBase) { lidarS = S.lidarSinCos[myRay.k]; lidarC = S.lidarSinCos[30 + myRay.k]; }
+    stage_world<NT>(S, p, sh, tid);
+    const int w = hdr.x;
+    if (w < 0) return;                                   // (empty slot of the last octet)
+    if (tid == 0) { sh.g.numWalls = hdr.y & 255; sh.g.numPlanes = (hdr.y >> 8) & 255; sh.present = 0; }
+    const int counts = hdr.z;
+    const int teams = hdr.w;
+    const int step = hdr.y >> 16;
     __syncthreads();
     const WorldGeom &g = sh.g;
     const int nAgents = cnt_agents(counts), nBoxes = cnt_boxes(counts), nRamps = cnt_ramps(counts);
-    const int visBase = obs_vis_base(A);
     if (HS_OBS_SKIP & 32) return;
     HS_OTICK(0)
     for (int item = tid; item < nAgents * kNumDSlots; item += NT) {
@@ -183,8 +185,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
 
     // ---------------- pass 1: ray setup, walls + planes, cull against the movable hulls ----------------
     for (int r = tid; r < NT; r += NT) {                       // (one trip: a lane per ray)
-        const RayId id = ray_id(r, visBase);
-        const int i = id.agent, k = id.k;
+        const int i = myRay.agent, k = myRay.k;
         sh.rayKey[r] = ray_key(-1.f, kKeyMiss);               // "no ray" (visibility ray not cast)
         if (i >= nAgents) continue;                            // (also the padding lanes between the two kinds)
         const int slot = kAgentSlot0 + i;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
         if (k < 30) {
             // lidarSystem: 30 rays in the agent's horizontal plane, t_max 200 (sim.cpp:727-738)
             const V3 right = {sh.right[i][0], sh.right[i][1], sh.right[i][2]};
-            const float s = sh.lidarSin[k], c = sh.lidarCos[k];
+            const float s = lidarS, c = lidarC;
             d = normalize(right * c + fwd * s);
             tmax = 200.f;
         } else {

@@ -975,7 +975,9 @@ HSD void physics_step(SimState &S, OctRes &R) {
     if (S.stepPar >= 0) {
         mem_sync();
         if (L == 0) {
+#ifndef HS_NO_RELEASE
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int ticket = __hip_atomic_fetch_add(&S.doneTickets[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&S.doneList[S.stepPar * noct + ticket], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -995,10 +997,14 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
 
 // Holds the stream of k_observe back until every wave of k_physics has started, i.e. holds its slot on a CU: the
 // waiting k_observe workgroups that follow can then never keep a physics wave from being placed.  One wave.
-__global__ void __launch_bounds__(64) k_gate(SimState S, int noct) {
+__global__ void __launch_bounds__(64) k_gate(SimState S, int noct, int doneFirst) {
     if (threadIdx.x != 0) return;
+    // ... and, optionally, until `doneFirst` physics waves have finished: k_observe then fills the slots the finished
+    // waves leave in the tail of k_physics instead of competing with the waves that are still in the middle of it
+    bool started = false;
     for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(&S.startedCount[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= noct) return;
+        if (!started) started = __hip_atomic_load(&S.startedCount[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= noct;
+        if (started && __hip_atomic_load(&S.doneTickets[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= doneFirst) return;
         __builtin_amdgcn_s_sleep(8);
     }
     S.status[2] = 2; *S.hostFlag = 1;      // (never observed; keeps a bug from hanging the GPU)

@@ -435,6 +435,11 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
     }
 }
 
+// Keeps SimState::slotHdr in step with the per-world scalars it mirrors.
+HSD void write_slot_hdr(const SimState &S, int w, int ps) {
+    S.slotHdr[ps] = make_int4(w, S.numWalls[w] | (S.numPlanes[w] << 8) | (S.curEpisodeStep[w] << 16), S.counts[w], S.teams[w]);
+}
+
 // resetSystem (src/sim.cpp:172-200) for one world
 HSD void reset_world(const SimState &S, int w) {
     int level = S.xReset[w];
@@ -443,9 +448,11 @@ HSD void reset_world(const SimState &S, int w) {
     if (level == 0) {
         S.curEpisodeStep[w] = step + 1;
         S.hiderTeamReward[w] = 1.f;
+        write_slot_hdr(S, w, S.slotOfWorld[w]);
         return;
     }
     regenerate_world<false>(S, w, level, nullptr);
+    write_slot_hdr(S, w, S.slotOfWorld[w]);
 }
 
 // Stand-alone launch: Manager::init (the Init task graph has no physics in front of the reset).  In a step the
@@ -456,6 +463,14 @@ __global__ void __launch_bounds__(64) k_reset(SimState S) {
     reset_world(S, w);
 }
 
+// lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent of every world; once per simulator.
+__global__ void __launch_bounds__(64) k_lidar_table(SimState S) {
+    const int k = threadIdx.x;
+    if (k >= 30) return;
+    const float theta = 2.f * kPi * ((float)k / 30.f) + kPi / 2.f;
+    hs_sincosf(theta, &S.lidarSinCos[k], &S.lidarSinCos[30 + k]);
+}
+
 // LoadCheckpoints graph, first node (sim.cpp:1324-1329); the trigger is left at 1 as sim.cpp:963 does.
 __global__ void __launch_bounds__(64) k_load_ckpt(SimState S) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,6 +478,7 @@ __global__ void __launch_bounds__(64) k_load_ckpt(SimState S) {
     if (S.xCkptCtrl[w] == 0) return;
     S.xCkptCtrl[w] = 1;
     regenerate_world<true>(S, w, 1, (const hs_checkpoint *)S.xCkpt + w);
+    write_slot_hdr(S, w, S.slotOfWorld[w]);
 }
 
 // SaveCheckpoints graph (sim.cpp:1315-1322): saveCheckpointSystem sim.cpp:1046-1137.

@@ -40,6 +40,11 @@ struct SimState {
     int *slotOfWorld;      // [N]
     int *worldOfSlot;      // [ceil(N / 8) * 8]  -1 = empty slot (padding of the last octet)
     int *loadAcc;          // [N] candidate pairs seen since the last k_balance
+    // What k_observe needs to know about the world in a slot, in slot order so that no load waits for worldOfSlot:
+    // {world id (-1: empty), numWalls | numPlanes << 8 | curEpisodeStep << 16, counts, teams}.  Rewritten by whoever
+    // changes one of them (write_slot_hdr: reset / level generation, checkpoint load, k_balance_commit).
+    int4 *slotHdr;         // [ceil(N / 8) * 8]
+    float *lidarSinCos;    // [60] hs_sincosf of the 30 lidar angles (sim.cpp:727-738), filled by k_lidar_table at hs_create
 
     // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
     Col<float, 3 * kNumDSlots> bpos;       // row = component * 17 + slot

@@ -242,7 +242,7 @@ class HideAndSeekSimulator:
                 "graphs_in_use": bool(st.graphs_in_use), "sched_error": int(st.sched_error)}
 
     def set_overlap(self, enabled):
-        """hs_set_overlap: the dependency schedule between k_physics and k_observe (default on); results are identical."""
+        """hs_set_overlap: the dependency schedule between k_physics and k_observe (default off, HS_OVERLAP=1); results are identical."""
         _check(self._L.hs_set_overlap(self._h, int(bool(enabled))))
 
     def warning(self):
