@@ -66,6 +66,7 @@ struct alignas(16) OctRes {
     unsigned short scInfo[kNumDSlots][kTile];   // per body: first static candidate | count << 8
     unsigned int scAcc[kTile];                  // bit k: static candidate k of the world has a manifold (set by the convex test)
     unsigned int ddAcc[kTile];                  // bit k: body-body candidate k has a manifold
+    unsigned int ddOrd[2][kTile];               // the accepted body-body candidates in solve order, 4 bits each (phase_dd)
     float plane0[4][kTile];                     // the ground plane nx, ny, nz, d of every world
     unsigned char bodies[kNumDSlots * kTile];   // compact list of existing bodies: slot << 3 | world
     unsigned char wallBodies[kNumDSlots * kTile];   // bodies with a wall / extra-plane manifold in this substep
@@ -490,14 +491,102 @@ HSD void solve_grab_joint_bodies(BodyS &A, BodyS &B, V3 r2, Q attach2, float sep
 
 // ------------------------------------------------------------------------------------------
 // Body-body manifolds (and grab joints), 8 lanes per world, all 8 worlds of the octet at once.  The oracle solves a
-// world's manifolds one after the other in (i<j) pair order; manifolds that share no body commute exactly, so lane q
-// takes the q-th accepted manifold of the sorted order and runs as soon as no EARLIER manifold that is still
-// pending touches one of its bodies.  Disjoint pairs are solved in one round instead of one after the other; the
-// result is bit-identical to the sequential order.
+// world's manifolds one after the other in (i<j) pair order; manifolds that share no body commute exactly, so the
+// h-th pair of lanes takes the h-th accepted manifold of the sorted order and runs as soon as no EARLIER manifold that
+// is still pending touches one of its bodies.  Disjoint pairs are solved in one round instead of one after the other;
+// the result is bit-identical to the sequential order.
+//
+// A manifold is solved by TWO lanes, one per body: everything a contact point does to body A is independent of what
+// it does to body B between the few scalars and points the two sides share (penetration, generalised inverse masses,
+// tangential drift), which the lanes exchange with a DPP swap.  Each lane evaluates exactly the expressions the
+// one-lane form (solve_point_position / solve_point_velocity <true>) evaluates for its body; the shared quantities
+// are sums and differences whose value does not depend on which side computes them (a + b = b + a, -(a - b) = b - a,
+// the sign of a dot product follows the sign of its vector argument exactly), so the results are the same bits.
+HSD float swap1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); }   // lanes 2k <-> 2k+1
+HSD V3 swap1(V3 v) { return {swap1(v.x), swap1(v.y), swap1(v.z)}; }
+
+// me: this lane's body; rl: its contact point (body frame); isA: this lane holds body A of the manifold.
+HSD float pair_point_position(BodyS &me, bool isA, V3 n, V3 rl, float muS) {
+    V3 rw = qrot(me.rot, rl);
+    V3 pm = me.pos + rw;
+    const float dm = dot(pm - swap1(pm), n);
+    float d = isA ? dm : -dm;                                     // dot(pA - pB, n)
+    if (!(d > 0.f)) return 0.f;
+    const V3 pprev = me.ppos + qrot(me.prot, rl);
+    const float dpm = dot(pprev - swap1(pprev), n);
+    const float dprev = isA ? dpm : -dpm;
+    const float excess = dprev - kMaxDepenVel * kSubstepH;
+    if (excess > 0.f) d = d - excess;
+    if (!(d > 0.f)) return 0.f;
+    const float wm = gen_inv_mass(me, rw, n);
+    const float wo = swap1(wm);                                   // (every lane swaps: never inside a branch on isA)
+    const float wsum = isA ? wm + wo : wo + wm;                   // wA + wB
+    if (!(wsum > 0.f)) return 0.f;
+    const float lam = d / wsum;
+    auto apply = [&](V3 p) {
+        if (!has_mass(me)) return;
+        const V3 dth = apply_inv_inertia(me, cross(rw, p));
+        if (isA) { me.pos = me.pos - p * me.invM; me.rot = quat_add_rotation(me.rot, -dth); }
+        else { me.pos = me.pos + p * me.invM; me.rot = quat_add_rotation(me.rot, dth); }
+    };
+    apply(n * lam);
+    rw = qrot(me.rot, rl);
+    pm = me.pos + rw;
+    const V3 mv = pm - pprev;                                     // how far this side's point has moved in the substep
+    const V3 ov = swap1(mv);
+    const V3 dp = isA ? mv - ov : ov - mv;                        // (pA - pAprev) - (pB - pBprev)
+    const V3 dpt = dp - n * dot(dp, n);
+    const float lt2 = len2(dpt);
+    if (lt2 > 1e-12f) {
+        const float wt = gen_inv_mass_sq(me, rw, dpt, lt2);
+        const float wto = swap1(wt);
+        const float wts = isA ? wt + wto : wto + wt;
+        if (wts > 0.f) {
+            const float lim = (muS * lam) * wts;
+            if ((lt2 * lt2) * lt2 < lim * lim) apply(dpt * (lt2 / wts));
+        }
+    }
+    return lam;
+}
+HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float muD) {
+    if (!(lamN > 0.f)) return;
+    const V3 rw = qrot(me.rot, rl);
+    const bool hm = me.invM + me.invI.x + me.invI.y + me.invI.z != 0.f;
+    const V3 vm = me.lin + cross(me.ang, rw);
+    const V3 vo = swap1(vm);
+    const bool ho = swap1(hm ? 1.f : 0.f) != 0.f;
+    const V3 vA = isA ? vm : vo, vB = isA ? vo : vm;
+    const bool hA = isA ? hm : ho, hB = isA ? ho : hm;
+    V3 v = {0.f, 0.f, 0.f};
+    if (hA) v = vA;
+    if (hB) v = v - vB;
+    const float vn = dot(n, v);
+    const V3 vt = v - n * vn;
+    const float vt2 = len2(vt);
+    V3 dv = -(n * vn);
+    if (vt2 > 1e-18f) {
+        const float vtl = sqrtf(vt2);
+        const float mag = fminf((muD * lamN) * kInvSubstepH, vtl);
+        dv = dv - vt * (mag / vtl);
+    }
+    const float dv2 = len2(dv);
+    if (!(dv2 > 1e-18f)) return;
+    const float wm = gen_inv_mass_sq(me, rw, dv, dv2);
+    const float wo = swap1(wm);
+    const float ws = isA ? wm + wo : wo + wm;
+    if (!(ws > 0.f)) return;
+    const V3 p = dv * (dv2 / ws);
+    const V3 da = apply_inv_inertia(me, cross(rw, p));
+    if (isA) { me.lin = me.lin + p * me.invM; me.ang = me.ang + da; }
+    else { me.lin = me.lin - p * me.invM; me.ang = me.ang - da; }
+}
+
 template <bool POS>
 HSD void phase_dd(const SimState &S, OctRes &R) {
-    constexpr int GL = 8;
+    constexpr int GL = 8, PAIRS = GL / 2;
     const int L = threadIdx.x, g = L / GL, q = L % GL;
+    const int h = q >> 1;                                         // this lane's pair within the world's 8 lanes
+    const bool isA = (q & 1) == 0;
     const int gbit0 = g * GL;                                     // first lane of this group in the wave
     const int w = S.wbeg + g;                                     // the world's slot in the tiled columns
     const int ndd = R.ndd[g];
@@ -519,63 +608,89 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
             rbody_store_pose(R, g, kAgentSlot0 + a, A); rbody_store_pose(R, g, other, B);
         }
     }
-    wave_sync();
     ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
-    // keys of the accepted candidates, kMaxDDCand = 16: lane q inspects candidates q and q+8
     const unsigned acc = R.ddAcc[g];
-    int key0 = 0x7fffffff, key1 = 0x7fffffff;
-    if (q < ndd && ((acc >> q) & 1u)) { const int p = R.ddPair[q][g]; key0 = ((p & 0xff) << 8) | (p >> 8); }
-    if (q + GL < ndd && ((acc >> (q + GL)) & 1u)) { const int p = R.ddPair[q + GL][g]; key1 = ((p & 0xff) << 8) | (p >> 8); }
-    // rank of every accepted candidate in sorted key order (keys are unique: distinct pairs)
-    int rank0 = 0, rank1 = 0, nacc = 0;
-#pragma unroll
-    for (int p = 0; p < GL; ++p) {
-        const int k0 = __shfl(key0, gbit0 + p), k1 = __shfl(key1, gbit0 + p);
-        rank0 += (k0 < key0) + (k1 < key0); rank1 += (k0 < key1) + (k1 < key1);
-        nacc += (k0 != 0x7fffffff) + (k1 != 0x7fffffff);
-    }
-    for (int base = 0; base < kMaxDDCand; base += GL) {
-        if (__ballot(base < nacc) == 0ull) break;
-        // lane q takes the manifold of rank base+q: find which lane/slot holds it
-        int mine = -1;
+    const int nacc = __popc(acc);
+    if (POS) {
+        // The solve order, once per substep (the velocity pass reuses it): kMaxDDCand = 16 candidates, lane q ranks the
+        // keys of the accepted ones among q and q+8 (keys are unique: distinct pairs) and enters them at their rank.
+        if (q < 2) R.ddOrd[q][g] = 0u;
+        int key0 = 0x7fffffff, key1 = 0x7fffffff;
+        if (q < ndd && ((acc >> q) & 1u)) { const int p = R.ddPair[q][g]; key0 = ((p & 0xff) << 8) | (p >> 8); }
+        if (q + GL < ndd && ((acc >> (q + GL)) & 1u)) { const int p = R.ddPair[q + GL][g]; key1 = ((p & 0xff) << 8) | (p >> 8); }
+        int rank0 = 0, rank1 = 0;
 #pragma unroll
         for (int p = 0; p < GL; ++p) {
-            const int r0 = __shfl(rank0, gbit0 + p), r1 = __shfl(rank1, gbit0 + p);
             const int k0 = __shfl(key0, gbit0 + p), k1 = __shfl(key1, gbit0 + p);
-            if (k0 != 0x7fffffff && r0 == base + q) mine = p;
-            if (k1 != 0x7fffffff && r1 == base + q) mine = p + GL;
+            rank0 += (k0 < key0) + (k1 < key0); rank1 += (k0 < key1) + (k1 < key1);
         }
+        wave_sync();
+        if (key0 != 0x7fffffff) atomicOr(&R.ddOrd[rank0 >> 3][g], (unsigned)q << ((rank0 & 7) * 4));
+        if (key1 != 0x7fffffff) atomicOr(&R.ddOrd[rank1 >> 3][g], (unsigned)(q + GL) << ((rank1 & 7) * 4));
+    }
+    wave_sync();
+    for (int base = 0; base < kMaxDDCand; base += PAIRS) {
+        if (__ballot(base < nacc) == 0ull) break;
+        // the h-th pair of lanes takes the manifold of rank base + h
+        const int rk = base + h;
+        const int mine = rk < nacc ? (int)((R.ddOrd[rk >> 3][g] >> ((rk & 7) * 4)) & 15u) : -1;
         int ma = -1, mb = -1;
         ManDD m;
         if (mine >= 0) { m = wsDD[mine]; ma = m.a; mb = m.b; }
+        // the earlier pairs of this batch that touch one of its bodies
+        unsigned dep = 0u;
+#pragma unroll
+        for (int p = 0; p < PAIRS - 1; ++p) {
+            const int pa = __shfl(ma, gbit0 + 2 * p), pb = __shfl(mb, gbit0 + 2 * p);
+            if (p < h && pa >= 0 && (pa == ma || pa == mb || pb == ma || pb == mb)) dep |= 1u << p;
+        }
         bool pending = mine >= 0;
+        BodyS me;
+        const int myBody = isA ? ma : mb;
+        const V3 n = ld3(m.n);
         while (true) {
-            const unsigned long long pend_mask = __ballot(pending);
+            const unsigned long long pend_mask = __ballot(pending && isA);
             if (pend_mask == 0ull) break;
-            bool ready = pending;
-#pragma unroll
-            for (int p = 0; p < GL; ++p) {
-                const int pa = __shfl(ma, gbit0 + p), pb = __shfl(mb, gbit0 + p);
-                const bool ppend = (pend_mask >> (gbit0 + p)) & 1ull;
-                if (p < q && ppend && (pa == ma || pa == mb || pb == ma || pb == mb)) ready = false;
-            }
-            if (ready) {
-                BodyS Ab, Bb;
-                rbody_load(R, g, m.a, Ab); rbody_load(R, g, m.b, Bb);
-                const V3 n = ld3(m.n);
-                if (POS) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < m.np) wsDD[mine].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
-                    rbody_store_pose(R, g, m.a, Ab); rbody_store_pose(R, g, m.b, Bb);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
-                    rbody_store_vel(R, g, m.a, Ab); rbody_store_vel(R, g, m.b, Bb);
+            // (bit 2p of the world's 8 bits: pair p is pending)
+            const unsigned wp = (unsigned)(pend_mask >> gbit0) & 0x55u;
+            const unsigned pendPairs = (wp & 1u) | ((wp >> 1) & 2u) | ((wp >> 2) & 4u) | ((wp >> 3) & 8u);
+#ifdef HS_DD_ONE_LANE
+            if (pending && (dep & pendPairs) == 0u) {
+                if (isA) {
+                    BodyS Ab, Bb;
+                    rbody_load(R, g, m.a, Ab); rbody_load(R, g, m.b, Bb);
+                    if (POS) {
+                        for (int j = 0; j < 4; ++j)
+                            if (j < m.np) wsDD[mine].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+                        rbody_store_pose(R, g, m.a, Ab); rbody_store_pose(R, g, m.b, Bb);
+                    } else {
+                        for (int j = 0; j < 4; ++j)
+                            if (j < m.np) solve_point_velocity<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), m.lam[j], m.muD);
+                        rbody_store_vel(R, g, m.a, Ab); rbody_store_vel(R, g, m.b, Bb);
+                    }
                 }
                 pending = false;
             }
+#else
+            if (pending && (dep & pendPairs) == 0u) {
+                rbody_load(R, g, myBody, me);
+                if (POS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < m.np) {
+                            const float lam = pair_point_position(me, isA, n, isA ? ld3(m.rA[j]) : ld3(m.rB[j]), m.muS);
+                            if (isA) wsDD[mine].lam[j] = m.lam[j] + lam;
+                        }
+                    rbody_store_pose(R, g, myBody, me);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < m.np) pair_point_velocity(me, isA, n, isA ? ld3(m.rA[j]) : ld3(m.rB[j]), m.lam[j], m.muD);
+                    rbody_store_vel(R, g, myBody, me);
+                }
+                pending = false;
+            }
+#endif
             wave_sync();                  // later rounds must see the poses / velocities just written
         }
     }
