@@ -249,6 +249,9 @@ int32_t hs_debug_phase_ticks(hs_sim *sim, int64_t *out, int32_t max_groups);
 /* The same for k_observe: ticks per section, summed over all waves: stage (incl. the schedule's wait), per-agent table,
  * ray setup, walls, planes, hull cull, exact hull tests, ray results, observation rows. */
 int32_t hs_debug_observe_ticks(hs_sim *sim, int64_t out[16]);
+/* ... and the work counters of the convex tests, summed over all waves and substeps: calls, box-shaped items, wedge
+ * items, rounds of 32 pairs, colliding pairs, contact-generation rounds. */
+int32_t hs_debug_sat_counters(hs_sim *sim, int64_t out[16]);
 
 /* Profiling aid: one dword-per-lane coalesced copy of `bytes` bytes (read + write), used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */

@@ -312,7 +312,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
     { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
-    HS_ALLOC(S.phaseTicks, 10 * (NP / hs::kTile) + 16 * 1024);     // + 1024 x 16 section counters of k_observe
+    HS_ALLOC(S.phaseTicks, 10 * (NP / hs::kTile) + 16 * 1024 + 16);     // + 1024 x 16 section counters of k_observe
     { const size_t G = NP / hs::kTile;
       if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
       HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
@@ -656,6 +656,13 @@ int32_t hs_debug_observe_ticks(hs_sim *s, int64_t out[16]) {
     HS_HIP(hipMemcpy(part.data(), s->S.phaseTicks + (size_t)10 * ((s->S.N + hs::kTile - 1) / hs::kTile), part.size() * sizeof(int64_t),
                      hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; ++i) { out[i] = 0; for (int b = 0; b < 1024; ++b) out[i] += part[(size_t)b * 16 + i]; }
+    return HS_OK;
+}
+// ... and the work counters of the convex tests: calls, box items, wedge items, rounds, colliding pairs, contact rounds.
+int32_t hs_debug_sat_counters(hs_sim *s, int64_t out[16]) {
+    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    HS_HIP(hipMemcpy(out, s->S.phaseTicks + (size_t)10 * ((s->S.N + hs::kTile - 1) / hs::kTile) + 16 * 1024, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return HS_OK;
 }
 

@@ -132,16 +132,21 @@ struct BodyReg {
 };
 
 // ------------------------------------------------------------------------------------------
-// Linear copies between the octet's blocks of the tiled columns and LDS.
+// Linear copies between the octet's blocks of the tiled columns and LDS, 16 bytes per lane and trip (a block is
+// ROWS x 8 words: a multiple of 32 bytes, and so is its offset in the column and in OctRes).
 template <typename T, int ROWS>
 HSD void copy_in(T *dst, const Col<T, ROWS> &col, int o) {
-    const T *src = col.octet(o);
-    for (int i = threadIdx.x; i < ROWS * kTile; i += 64) dst[i] = src[i];
+    static_assert(sizeof(T) == 4 && (ROWS * kTile) % 4 == 0, "16-byte pieces");
+    const float4 *src = reinterpret_cast<const float4 *>(col.octet(o));
+    float4 *d = reinterpret_cast<float4 *>(dst);
+    for (int i = threadIdx.x; i < ROWS * kTile / 4; i += 64) d[i] = src[i];
 }
 template <typename T, int ROWS>
 HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
-    T *dst = col.octet(o);
-    for (int i = threadIdx.x; i < ROWS * kTile; i += 64) dst[i] = src[i];
+    static_assert(sizeof(T) == 4 && (ROWS * kTile) % 4 == 0, "16-byte pieces");
+    float4 *dst = reinterpret_cast<float4 *>(col.octet(o));
+    const float4 *s = reinterpret_cast<const float4 *>(src);
+    for (int i = threadIdx.x; i < ROWS * kTile / 4; i += 64) dst[i] = s[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -221,33 +226,37 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         if (have[jb]) { lo[jb] = rld3(R.u.det.lo, slot, g); hi[jb] = rld3(R.u.det.hi, slot, g); }
     }
     // The loops run over the OTHER body / the wall, each read from LDS once and tested against all of the lane's slots.
+    // (no branch on the other body's presence: the loads of several trips are in flight together)
 #pragma unroll 4
     for (int j = 1; j < NS; ++j) {
         const int mj = R.meta[j][g];
-        if (mj == 0) continue;
         const bool dynj = meta_resp(mj) == RESP_DYNAMIC;
         const V3 loj = rld3(R.u.det.lo, j, g), hij = rld3(R.u.det.hi, j, g);
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
-            if (have[jb] && l + jb * G < j && (dynamic[jb] || dynj) &&
-                lo[jb].x <= hij.x && loj.x <= hi[jb].x && lo[jb].y <= hij.y && loj.y <= hi[jb].y &&
-                lo[jb].z <= hij.z && loj.z <= hi[jb].z) dd_mask[jb] |= 1u << j;
+            const bool hit = (mj != 0) & have[jb] & (l + jb * G < j) & (dynamic[jb] | dynj) &
+                (lo[jb].x <= hij.x) & (loj.x <= hi[jb].x) & (lo[jb].y <= hij.y) & (loj.y <= hi[jb].y) &
+                (lo[jb].z <= hij.z) & (loj.z <= hi[jb].z);
+            dd_mask[jb] |= hit ? 1u << j : 0u;
         }
     }
-#pragma unroll 4
-    for (int k = 0; k < nwl; ++k) {
-        float cx, cy, hx, hy;
-        if (k < kLdsWalls) { cx = R.u.det.wall[0][k][g]; cy = R.u.det.wall[1][k][g]; hx = R.u.det.wall[2][k][g]; hy = R.u.det.wall[3][k][g]; }
-        else {
-            const int w = S.wbeg + g;
-            cx = S.walls(0 * kMaxWalls + k, w); cy = S.walls(1 * kMaxWalls + k, w); hx = S.walls(2 * kMaxWalls + k, w); hy = S.walls(3 * kMaxWalls + k, w);
-        }
+    bool zin[JB];                                       // the walls all span z in [0, 2.5]
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) zin[jb] = dynamic[jb] & (lo[jb].z <= 2.5f) & (0.f <= hi[jb].z);
+    auto wall_test = [&](int k, float cx, float cy, float hx, float hy) {
         const float wx0 = cx - hx, wx1 = cx + hx, wy0 = cy - hy, wy1 = cy + hy;
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
-            if (dynamic[jb] && lo[jb].x <= wx1 && wx0 <= hi[jb].x && lo[jb].y <= wy1 && wy0 <= hi[jb].y &&
-                lo[jb].z <= 2.5f && 0.f <= hi[jb].z) s_mask[jb] |= 1ull << k;
+            const bool hit = zin[jb] & (lo[jb].x <= wx1) & (wx0 <= hi[jb].x) & (lo[jb].y <= wy1) & (wy0 <= hi[jb].y);
+            s_mask[jb] |= hit ? 1ull << k : 0ull;
         }
+    };
+    const int nwLds = nwl < kLdsWalls ? nwl : kLdsWalls;
+#pragma unroll 4
+    for (int k = 0; k < nwLds; ++k) wall_test(k, R.u.det.wall[0][k][g], R.u.det.wall[1][k][g], R.u.det.wall[2][k][g], R.u.det.wall[3][k][g]);
+    for (int k = kLdsWalls; k < nwl; ++k) {             // (the few walls beyond the staged ones, from global memory)
+        const int w = S.wbeg + g;
+        wall_test(k, S.walls(0 * kMaxWalls + k, w), S.walls(1 * kMaxWalls + k, w), S.walls(2 * kMaxWalls + k, w), S.walls(3 * kMaxWalls + k, w));
     }
     // candidate slots in the world's lists: prefix sums in body-slot order (slots l of all lanes, then l + 8, ...),
     // i.e. the oracle's candidate order — so even the pairs dropped beyond the capacity are the oracle's
@@ -401,7 +410,15 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
     const int lane = threadIdx.x & 63;
     const bool hi = lane >= kClipLanes;
     int npend = 0;
+    int nhit_total = 0, nflush = 0;      // (counters of the HS_PHASE_TIMING build)
+#ifdef HS_SAT_COUNTERS
+    long long tflush = 0, twedge = 0; const long long tsat0 = wall_clock64();
+#define HS_SAT_T(x) x
+#else
+#define HS_SAT_T(x)
+#endif
     for (int base = 0; base < total; base += kClipLanes) {
+        HS_SAT_T(const long long tr0_ = wall_clock64();)
         const int it = base + (lane & (kClipLanes - 1));
         AxisResult res = {0, {0.f, 0.f, 0.f}};
         int item = 0;
@@ -437,11 +454,13 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                 res = sat_axes(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), hi);
             }
         }
+        HS_SAT_T(if (ic.nwedge > 0 && base >= wedge0) twedge += wall_clock64() - tr0_;)
         // the colliding pairs of this round join the pending list (their low lanes hold the results)
         const bool hit = !hi && res.code != 0;
         const unsigned long long m = __ballot(hit);
         const int nhit = __popcll(m);
-        if (npend + nhit > kClipLanes) { wave_sync(); sat_flush(S, R, npend); npend = 0; }
+        if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) sat_flush(S, R, npend); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
+        nhit_total += nhit;
         if (hit) {
             const int pos = npend + __popcll(m & ((1ull << lane) - 1ull));
             R.u.sat.pend[0][pos] = item; R.u.sat.pend[1][pos] = res.code;
@@ -450,8 +469,17 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         npend += nhit;
     }
     wave_sync();
-    if (npend > 0) sat_flush(S, R, npend);
+    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) sat_flush(S, R, npend); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; }
     mem_sync();           // the manifolds (global memory) are complete for the lanes that solve them
+#ifdef HS_SAT_COUNTERS
+    if (lane == 0) {      // work counters of the convex tests (tools/phase_timing.py; their atomics disturb the phase times)
+        unsigned long long *c = (unsigned long long *)S.phaseTicks + (size_t)10 * gridDim.x + 16 * 1024;
+        atomicAdd(&c[0], 1ull); atomicAdd(&c[1], (unsigned long long)ic.nbox); atomicAdd(&c[2], (unsigned long long)ic.nwedge);
+        atomicAdd(&c[3], (unsigned long long)((total + kClipLanes - 1) / kClipLanes)); atomicAdd(&c[4], (unsigned long long)nhit_total);
+        atomicAdd(&c[5], (unsigned long long)nflush);
+        atomicAdd(&c[6], (unsigned long long)tflush); atomicAdd(&c[7], (unsigned long long)(wall_clock64() - tsat0)); atomicAdd(&c[8], (unsigned long long)twedge);
+    }
+#endif
 }
 
 // Fixed grab joint on two loaded bodies (sim.cpp:343-356): angular alignment, then anchor coincidence.

@@ -42,3 +42,10 @@ if L.hs_debug_observe_ticks(sim._h, ob.ctypes.data) == 0:
     for i, nm in enumerate(onames):
         print(f"{nm:18s} {ob[i] / 100.0 / launches / waves:10.2f} {100.0 * ob[i] / max(tot, 1):8.1f} %")
     print(f"pairs per world per launch: {ob[9] / launches / N:.1f} box-shaped, {ob[10] / launches / N:.1f} ramps")
+sc = np.zeros(16, np.int64)
+L.hs_debug_sat_counters.argtypes = [C.c_void_p, C.c_void_p]
+if L.hs_debug_sat_counters(sim._h, sc.ctypes.data) == 0 and sc[0] > 0:
+    c = float(sc[0])
+    print(f"convex tests per wave and substep: {sc[1] / c:.1f} box-shaped items + {sc[2] / c:.1f} wedge items in {sc[3] / c:.2f} rounds of 32; "
+          f"{sc[4] / c:.1f} colliding pairs in {sc[5] / c:.2f} contact rounds")
+    print(f"  time per call: {sc[7] / c / 100:.2f} us, of which contact generation {sc[6] / c / 100:.2f} us, wedge rounds {sc[8] / c / 100:.2f} us")
