@@ -52,6 +52,7 @@ struct hs_sim {
     int slots = 0;                         // physics waves the device holds at once (8 per CU: LDS)
     hipStream_t step_stream = nullptr;     // the stream of the open step
     bool blocking_own_stream = false;      // HS_STREAM=own: hs_step uses the handle's stream as hs_step_begin does
+    int step_idx = 0;                      // physics launches mod 3 (SimState::tickSum)
     int gate_pct = 0;                      // k_observe starts when this share of the physics waves has finished (HS_GATE_PCT)
     int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
     hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
@@ -117,6 +118,7 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     // (8 slots of slack: k_gate and the first k_observe workgroups must never take a slot that a physics wave still needs)
     const bool overlap = allow_overlap && s->overlap && !first && stages == 7 && !skip_obs && noct + 8 <= s->slots;
     S.stepPar = overlap ? s->sched_par : -1;
+    S.stepIdx = s->step_idx; if (!first && (stages & 1)) s->step_idx = (s->step_idx + 1) % 3;
     s->overlapped_last = false;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     // (a blocking hs_step has synchronised everything before and joins the two streams on the host: cross-stream
@@ -320,6 +322,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N);
     if ((rc = s->dalloc(&S.slotHdr, NP, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }      // world id -1: empty slot
     HS_ALLOC(S.lidarSinCos, 60);
+    HS_ALLOC(S.octTicks, NP / hs::kTile); HS_ALLOC(S.tickSum, 3);
     HS_ALLOC(s->bal_hist, hs::kBalanceBins); HS_ALLOC(s->bal_cursor, hs::kBalanceBins); HS_ALLOC(s->bal_new_slot, N);
     { char *tmp; s->bal_tmp_bytes = (size_t)S.walls.kRows * NP * sizeof(float); HS_ALLOC(tmp, s->bal_tmp_bytes); s->bal_tmp = tmp; }
     HS_ALLOC(S.status, 4);

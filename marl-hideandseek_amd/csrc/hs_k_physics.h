@@ -1003,7 +1003,22 @@ HSD void physics_step(SimState &S, OctRes &R) {
     const int noct = gridDim.x;
     // The launch ends with its slowest wave, and under the dependency schedule k_observe's workgroups run on the same
     // SIMDs beside the physics waves that are still at work: those keep the first claim on the issue slots.
-    __builtin_amdgcn_s_setprio(3);
+    // ... and among the physics waves the ones that were slow in the previous step (the same worlds: contact piles
+    // persist) go first on their SIMD: the launch ends with its slowest wave, and the partner of a slow wave has slack.
+    // Measured: k_physics 0.387 -> 0.380 ms; boosting a wave while it is inside a chain of manifolds or an extra round
+    // of convex tests instead gave 0.382.
+    const long long tStart = wall_clock64();
+    {
+        const int sidx = S.stepIdx, prevIdx = sidx == 0 ? 2 : sidx - 1, nextIdx = sidx == 2 ? 0 : sidx + 1;
+        if (o == 0 && L == 0) S.tickSum[nextIdx] = 0ull;
+        const float mean = (float)S.tickSum[prevIdx] / (float)noct, mine = (float)S.octTicks[o];
+        const bool known = mean > 0.f;
+        if (known && mine > 1.10f * mean) __builtin_amdgcn_s_setprio(3);
+        else if (known && mine > 0.98f * mean) __builtin_amdgcn_s_setprio(2);
+        else if (known && mine > 0.88f * mean) __builtin_amdgcn_s_setprio(1);
+        else if (known) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+    }
     if (S.stepPar >= 0 && L == 0) {                   // dependency schedule: clear the next step's half of the finish list
         const int pn = S.stepPar ^ 1;
         S.doneList[pn * noct + o] = -1;
@@ -1125,6 +1140,11 @@ HSD void physics_step(SimState &S, OctRes &R) {
             const int ticket = __hip_atomic_fetch_add(&S.doneTickets[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&S.doneList[S.stepPar * noct + ticket], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (L == 0) {
+        const int dt = (int)(wall_clock64() - tStart);
+        S.octTicks[o] = dt;
+        atomicAdd(&S.tickSum[S.stepIdx], (unsigned long long)dt);
     }
 #ifdef HS_PHASE_TIMING
     if (L == 0) for (int i = 0; i < 10; ++i) S.phaseTicks[(size_t)o * 10 + i] += acc[i];

@@ -44,6 +44,11 @@ struct SimState {
     // {world id (-1: empty), numWalls | numPlanes << 8 | curEpisodeStep << 16, counts, teams}.  Rewritten by whoever
     // changes one of them (write_slot_hdr: reset / level generation, checkpoint load, k_balance_commit).
     int4 *slotHdr;         // [ceil(N / 8) * 8]
+    // How long each physics wave took in the previous step (100 MHz ticks) and the sums over all waves of the last
+    // three steps: a wave that was slower than the average raises its issue priority (hs_k_physics.h).
+    int *octTicks;         // [octets]
+    unsigned long long *tickSum;   // [3], indexed by stepIdx
+    int stepIdx;           // launch counter mod 3
     float *lidarSinCos;    // [60] hs_sincosf of the 30 lidar angles (sim.cpp:727-738), filled by k_lidar_table at hs_create
 
     // --- movable bodies: 17 slots (9 boxes, 2 ramps, 6 agents)
