@@ -47,6 +47,14 @@ def build_smallcap(force=False):
     return build_lib(force=force, out=SMALLCAP_LIB, defines=("HS_MAX_DD_CAND=1", "HS_MAX_S_CAND=1"))
 
 
+# Development build with per-phase timers in the kernels (tools/phase_timing.py, tools/phase_tail.py).
+TIMING_LIB = os.path.join(HERE, "lib", "libhideseek_timing.so")
+
+
+def build_timing(force=False, counters=False):
+    return build_lib(force=force, out=TIMING_LIB, defines=("HS_PHASE_TIMING",) + (("HS_SAT_COUNTERS",) if counters else ()))
+
+
 def build_headless():
     """C++ headless driver over the C ABI (reference: src/headless.cpp)."""
     out = os.path.join(HERE, "lib", "headless")
@@ -62,3 +70,5 @@ if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
     print(build_headless())
     print(build_smallcap(force="--force" in sys.argv))
+    if "--timing" in sys.argv:
+        print(build_timing(force="--force" in sys.argv, counters="--sat-counters" in sys.argv))

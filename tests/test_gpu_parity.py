@@ -95,6 +95,14 @@ def test_default_mode_full_actions_variable_team_sizes(oracle):
     drive(sim, ref, gt, 110, "full", check_every=5)
 
 
+@pytest.mark.parametrize("hiders,seekers", [((1, 1), (1, 1)), ((1, 2), (1, 1)), ((2, 2), (1, 1))])
+def test_small_teams_in_training_levels(oracle, hiders, seekers):
+    """2 and 3 agents per world in generated levels: k_observe's 128- and 192-thread instantiations with their own
+    lidar / visibility lane layouts, and physics octets with few bodies, across the 96th step (rewards start)."""
+    sim, ref, gt = make_pair(oracle, 40, seed=21, hiders=hiders, seekers=seekers)
+    drive(sim, ref, gt, 100, "full", check_every=5)
+
+
 @pytest.mark.parametrize("level", [2, 3, 4, 5, 6, 7, 8])
 def test_debug_levels(oracle, level):
     """generateDebugEnvironment scenes (level_gen.cpp:336-526) as physics fixtures."""

@@ -1,8 +1,8 @@
-"""Per-phase time of the persistent physics kernel (development aid).
+"""Per-phase time of the physics kernel and per-section time of k_observe (development aid).
 
-Needs a library built with -DHS_PHASE_TIMING (pass it through HS_LIB_PATH):
-  hipcc <build.py flags> -DHS_PHASE_TIMING -o variants/lib_timing.so marl-hideandseek_amd/csrc/hideseek.hip
-  HS_LIB_PATH=$PWD/variants/lib_timing.so python tools/phase_timing.py 16000
+Needs the timing build of the library (python marl-hideandseek_amd/build.py --timing [--sat-counters]):
+  HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so python tools/phase_timing.py 16000
+--sat-counters adds the work counters of the convex tests (their atomics disturb the phase times).
 """
 import os, sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "marl-hideandseek_amd"))
