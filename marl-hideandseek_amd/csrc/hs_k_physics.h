@@ -61,8 +61,8 @@ struct alignas(16) OctRes {
             int pend[5][kClipLanes];                                    // colliding pairs waiting for contact generation: item, axis code, axis xyz
         } sat;
     } u;
-    unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 8
-    unsigned short scPair[kMaxSCand][kTile];    // body | static << 8  (static = wall index, 36 + plane index)
+    unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 5 | manifold location << 11 (pair_*() below)
+    unsigned short scPair[kMaxSCand][kTile];    // body | static << 5 | location << 11  (static = wall index, 36 + plane index)
     unsigned short scInfo[kNumDSlots][kTile];   // per body: first static candidate | count << 8
     unsigned int scAcc[kTile];                  // bit k: static candidate k of the world has a manifold (set by the convex test)
     unsigned int ddAcc[kTile];                  // bit k: body-body candidate k has a manifold
@@ -76,6 +76,37 @@ struct alignas(16) OctRes {
 };
 static_assert(sizeof(OctRes) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
 static_assert(offsetof(OctRes, u.sat.items) >= offsetof(OctRes, u.det.wall), "items must not overlap the AABBs");
+
+// ---- candidate pairs and where their contact manifolds live ----
+// A manifold produced by the LAST contact-generation round of a substep (nearly always the only one) stays in LDS:
+// lane i of that round writes it over its own column of the clip buffers (words k * 32 + i: the lane's own clipping
+// scratch, dead by then — no other lane ever touches that column), where the solver phases of the substep read it.
+// Columns 0..30 are slots; location 31 = the manifold is in the global workspace (S.wsDD / S.wsSC): earlier rounds of
+// a substep with more than 32 colliding pairs, the 32nd lane of the last round, extra planes of the debug levels.
+constexpr int kLocGlobal = 31;
+HSD int pair_a(int p) { return p & 31; }
+HSD int pair_b(int p) { return (p >> 5) & 63; }
+HSD int pair_loc(int p) { return (p >> 11) & 31; }
+HSD int pair_pack(int a, int b) { return a | (b << 5) | (kLocGlobal << 11); }
+static_assert(kNumDSlots <= 32 && kMaxWalls + kMaxPlanes <= 64, "pair encoding");
+static_assert(sizeof(ManDD) / 4 * kClipLanes <= kClipWords, "a manifold fits the lane's clip column");
+template <typename M> HSD void man_lds_store(float *clip, int slot, const M &m) {
+    int w[sizeof(M) / 4];
+    __builtin_memcpy(w, &m, sizeof(M));
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(M) / 4); ++k) ((int *)clip)[k * kClipLanes + slot] = w[k];
+}
+template <typename M> HSD void man_lds_load(const float *clip, int slot, M &m) {
+    int w[sizeof(M) / 4];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(M) / 4); ++k) w[k] = ((const int *)clip)[k * kClipLanes + slot];
+    __builtin_memcpy(&m, w, sizeof(M));
+}
+// accumulated normal multipliers of a manifold in LDS: the last 4 words of either record
+template <typename M> HSD void man_lds_set_lam(float *clip, int slot, int j, float v) {
+    static_assert(offsetof(M, lam) == sizeof(M) - 16, "lam is the record's tail");
+    clip[(sizeof(M) / 4 - 4 + j) * kClipLanes + slot] = v;
+}
 
 // ---- accessors of the resident columns ----
 template <int C> HSD V3 rld3(const float (&a)[C][kNumDSlots][kTile], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g]}; }
@@ -310,7 +341,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         unsigned mm = dd_mask[jb]; int i = 0;
         while (mm && i < add[jb]) {
             const int j = __ffs(mm) - 1; mm &= mm - 1;
-            R.ddPair[bdd[jb] + i][g] = (unsigned short)(slot | (j << 8));
+            R.ddPair[bdd[jb] + i][g] = (unsigned short)pair_pack(slot, j);
             const unsigned short item = (unsigned short)((g << 6) | (bdd[jb] + i));
             if (ramp || (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps)) R.u.sat.items[iwedge++] = item; else R.u.sat.items[ibox++] = item;
             ++i;
@@ -321,7 +352,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         while (sm && i < asc[jb]) {
             const int bit = __ffsll((long long)sm) - 1; sm &= sm - 1;
             const int k = bit < kMaxPlanes ? kMaxWalls + bit : bit - kMaxPlanes;
-            R.scPair[bsc[jb] + i][g] = (unsigned short)(slot | (k << 8));
+            R.scPair[bsc[jb] + i][g] = (unsigned short)pair_pack(slot, k);
             const unsigned short item = (unsigned short)((g << 6) | 32 | (bsc[jb] + i));
             if (ramp) R.u.sat.items[iwedge++] = item; else R.u.sat.items[ibox++] = item;
             ++i;
@@ -349,9 +380,12 @@ HSD HullSrc sat_hull_b(const SimState &S, const OctRes &R, int g, int w, bool is
     return hull_src_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
                          S.walls(2 * kMaxWalls + bsel, w), S.walls(3 * kMaxWalls + bsel, w));
 }
-// stage 2 for the first `npend` pending pairs: lane i < 32 takes pair i
-HSD void sat_flush(const SimState &S, OctRes &R, int npend) {
+// stage 2 for the first `npend` pending pairs: lane i < 32 takes pair i.  `last`: this is the substep's last round,
+// whose manifolds stay in LDS (in the lane's own clip column); returns whether a manifold went to global memory.
+HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
     const int lane = threadIdx.x & 63;
+    const bool toLds = last && lane < kLocGlobal;
+    bool wroteGlobal = false;
     if (lane < npend) {
         const int item = R.u.sat.pend[0][lane];
         AxisResult res;
@@ -362,7 +396,7 @@ HSD void sat_flush(const SimState &S, OctRes &R, int npend) {
         const bool isdd = idx < 32;
         const int kk = idx & 31;
         const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
-        const int a = pair & 0xff, bsel = pair >> 8;
+        const int a = pair_a(pair), bsel = pair_b(pair);
         const ClipBuf cb = {R.u.sat.clip, lane};
         RawManifold raw;
         if (sat_contact(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), res, cb, raw)) {
@@ -384,7 +418,8 @@ HSD void sat_flush(const SimState &S, OctRes &R, int npend) {
                     st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
                     m.lam[j] = 0.f;
                 }
-                ((ManDD *)S.wsDD + (size_t)w * kMaxDDCand)[kk] = m;
+                if (toLds) { man_lds_store(R.u.sat.clip, lane, m); R.ddPair[kk][g] = (unsigned short)((pair & 0x7ff) | (lane << 11)); }
+                else { ((ManDD *)S.wsDD + (size_t)w * kMaxDDCand)[kk] = m; wroteGlobal = true; }
                 atomicOr(&R.ddAcc[g], 1u << kk);
             } else {
                 ManS m;
@@ -396,20 +431,25 @@ HSD void sat_flush(const SimState &S, OctRes &R, int npend) {
                     st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
                     m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                 }
-                ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m;
+                if (toLds) { man_lds_store(R.u.sat.clip, lane, m); R.scPair[kk][g] = (unsigned short)((pair & 0x7ff) | (lane << 11)); }
+                else { ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m; wroteGlobal = true; }
                 atomicOr(&R.scAcc[g], 1u << kk);
             }
         }
     }
     wave_sync();
+    return __ballot(wroteGlobal) != 0ull;
 }
-HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
+// Returns whether any manifold of the substep lies in the global workspace (wave-uniform): only then do the solver
+// phases have to wait for global memory at all.
+HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
     static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     const int total = ic.nwedge > 0 ? wedge0 + ic.nwedge : ic.nbox;
     const int lane = threadIdx.x & 63;
     const bool hi = lane >= kClipLanes;
     int npend = 0;
+    bool usedGlobal = false, planeMan = false;
     int nhit_total = 0, nflush = 0;      // (counters of the HS_PHASE_TIMING build)
 #ifdef HS_SAT_COUNTERS
     long long tflush = 0, twedge = 0; const long long tsat0 = wall_clock64();
@@ -429,7 +469,7 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
             const bool isdd = idx < 32;
             const int kk = idx & 31;
             const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
-            const int a = pair & 0xff, bsel = pair >> 8;
+            const int a = pair_a(pair), bsel = pair_b(pair);
             if (!isdd && bsel >= kMaxWalls) {
                 // extra planes (debug levels only): hull against plane, no axis search
                 const int oa = meta_obj(R.meta[a][g]);
@@ -449,6 +489,7 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                     }
                     ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m;
                     atomicOr(&R.scAcc[g], 1u << kk);
+                    planeMan = true;
                 }
             } else {
                 res = sat_axes(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), hi);
@@ -459,7 +500,7 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         const bool hit = !hi && res.code != 0;
         const unsigned long long m = __ballot(hit);
         const int nhit = __popcll(m);
-        if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) sat_flush(S, R, npend); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
+        if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, false); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
         nhit_total += nhit;
         if (hit) {
             const int pos = npend + __popcll(m & ((1ull << lane) - 1ull));
@@ -469,8 +510,9 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         npend += nhit;
     }
     wave_sync();
-    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) sat_flush(S, R, npend); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; }
-    mem_sync();           // the manifolds (global memory) are complete for the lanes that solve them
+    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, true); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; }
+    usedGlobal |= __ballot(planeMan) != 0ull;
+    if (usedGlobal) mem_sync();          // the manifolds in global memory are complete for the lanes that solve them
 #ifdef HS_SAT_COUNTERS
     if (lane == 0) {      // work counters of the convex tests (tools/phase_timing.py; their atomics disturb the phase times)
         unsigned long long *c = (unsigned long long *)S.phaseTicks + (size_t)10 * gridDim.x + 16 * 1024;
@@ -480,6 +522,7 @@ HSD void phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         atomicAdd(&c[6], (unsigned long long)tflush); atomicAdd(&c[7], (unsigned long long)(wall_clock64() - tsat0)); atomicAdd(&c[8], (unsigned long long)twedge);
     }
 #endif
+    return usedGlobal;
 }
 
 // Fixed grab joint on two loaded bodies (sim.cpp:343-356): angular alignment, then anchor coincidence.
@@ -644,8 +687,8 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
         // keys of the accepted ones among q and q+8 (keys are unique: distinct pairs) and enters them at their rank.
         if (q < 2) R.ddOrd[q][g] = 0u;
         int key0 = 0x7fffffff, key1 = 0x7fffffff;
-        if (q < ndd && ((acc >> q) & 1u)) { const int p = R.ddPair[q][g]; key0 = ((p & 0xff) << 8) | (p >> 8); }
-        if (q + GL < ndd && ((acc >> (q + GL)) & 1u)) { const int p = R.ddPair[q + GL][g]; key1 = ((p & 0xff) << 8) | (p >> 8); }
+        if (q < ndd && ((acc >> q) & 1u)) { const int p = R.ddPair[q][g]; key0 = (pair_a(p) << 8) | pair_b(p); }
+        if (q + GL < ndd && ((acc >> (q + GL)) & 1u)) { const int p = R.ddPair[q + GL][g]; key1 = (pair_a(p) << 8) | pair_b(p); }
         int rank0 = 0, rank1 = 0;
 #pragma unroll
         for (int p = 0; p < GL; ++p) {
@@ -662,9 +705,13 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
         // the h-th pair of lanes takes the manifold of rank base + h
         const int rk = base + h;
         const int mine = rk < nacc ? (int)((R.ddOrd[rk >> 3][g] >> ((rk & 7) * 4)) & 15u) : -1;
-        int ma = -1, mb = -1;
+        int ma = -1, mb = -1, loc = kLocGlobal;
         ManDD m;
-        if (mine >= 0) { m = wsDD[mine]; ma = m.a; mb = m.b; }
+        if (mine >= 0) {
+            const int pr = R.ddPair[mine][g];
+            ma = pair_a(pr); mb = pair_b(pr); loc = pair_loc(pr);
+            if (loc != kLocGlobal) man_lds_load(R.u.sat.clip, loc, m); else m = wsDD[mine];
+        }
         // the earlier pairs of this batch that touch one of its bodies
         unsigned dep = 0u;
 #pragma unroll
@@ -689,7 +736,10 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
                     rbody_load(R, g, m.a, Ab); rbody_load(R, g, m.b, Bb);
                     if (POS) {
                         for (int j = 0; j < 4; ++j)
-                            if (j < m.np) wsDD[mine].lam[j] = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+                            if (j < m.np) {
+                                const float lam = m.lam[j] + solve_point_position<true>(Ab, Bb, n, ld3(m.rA[j]), ld3(m.rB[j]), 0.f, m.muS);
+                                if (loc != kLocGlobal) man_lds_set_lam<ManDD>(R.u.sat.clip, loc, j, lam); else wsDD[mine].lam[j] = lam;
+                            }
                         rbody_store_pose(R, g, m.a, Ab); rbody_store_pose(R, g, m.b, Bb);
                     } else {
                         for (int j = 0; j < 4; ++j)
@@ -707,7 +757,7 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
                     for (int j = 0; j < 4; ++j)
                         if (j < m.np) {
                             const float lam = pair_point_position(me, isA, n, isA ? ld3(m.rA[j]) : ld3(m.rB[j]), m.muS);
-                            if (isA) wsDD[mine].lam[j] = m.lam[j] + lam;
+                            if (isA) { if (loc != kLocGlobal) man_lds_set_lam<ManDD>(R.u.sat.clip, loc, j, m.lam[j] + lam); else wsDD[mine].lam[j] = m.lam[j] + lam; }
                         }
                     rbody_store_pose(R, g, myBody, me);
                 } else {
@@ -790,13 +840,18 @@ HSD void wall_round(const SimState &S, OctRes &R, int nwb) {
 #pragma unroll 1
         for (int k = bsc; k < bsc + asc; ++k) {
             if (!((acc >> k) & 1u)) continue;
-            const ManS m = wsSC[k];
+            const int loc = pair_loc(R.scPair[k][g]);
+            ManS m;
+            if (loc != kLocGlobal) man_lds_load(R.u.sat.clip, loc, m); else m = wsSC[k];
             body_refresh_inertia(me);
             const V3 n = ld3(m.n);
             if (POS) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < m.np) wsSC[k].lam[j] = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+                    if (j < m.np) {
+                        const float lam = m.lam[j] + solve_point_position<false>(me, none, n, ld3(m.rA[j]), V3{0.f, 0.f, 0.f}, m.offB[j], m.muS);
+                        if (loc != kLocGlobal) man_lds_set_lam<ManS>(R.u.sat.clip, loc, j, lam); else wsSC[k].lam[j] = lam;
+                    }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1090,7 +1145,7 @@ HSD void physics_step(SimState &S, OctRes &R) {
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect<ROUNDS>(S, R, NS);
         HS_TICK(2)
-        phase_sat(S, R, ic);
+        const bool manGlobal = phase_sat(S, R, ic);
         HS_TICK(3)
         phase_dd<true>(S, R);
         HS_TICK(4)
@@ -1101,7 +1156,7 @@ HSD void physics_step(SimState &S, OctRes &R) {
         if (nwb > 0) { wall_round<true>(S, R, nwb); wave_sync(); }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
-        mem_sync();                       // (also: the wall manifolds' multipliers for the velocity pass)
+        if (manGlobal) mem_sync(); else wave_sync();   // (the multipliers of manifolds in the global workspace, for the velocity pass)
         HS_TICK(5)
         phase_dd<false>(S, R);
         HS_TICK(6)
