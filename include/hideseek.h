@@ -15,6 +15,7 @@
 #ifndef HIDESEEK_H
 #define HIDESEEK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -44,7 +45,11 @@ enum {
     HS_FLAG_ZERO_AGENT_VELOCITY = 1 << 3,
     /* extension: skip the observation task-graph nodes (sim.cpp:1232-1293) — the physics-only
        roofline configuration of BASELINE.json configs[2]; not a reference flag. */
-    HS_FLAG_EXT_SKIP_OBSERVATIONS = 1 << 16
+    HS_FLAG_EXT_SKIP_OBSERVATIONS = 1 << 16,
+    /* extension: render the agent views (depth + RGB, hs_render below) as part of every init / step when
+       enable_batch_renderer is set.  Without it the renderer outputs stay allocated and unwritten, which is what the
+       reference scripts' arguments get (scripts/benchmark.py:32,47 only takes the tensor). */
+    HS_FLAG_EXT_RENDER = 1 << 17
 };
 
 /* Manager::Config (src/mgr.hpp:16-32) + the shard placement of SURVEY §8e. */
@@ -56,7 +61,7 @@ typedef struct hs_config {
     uint32_t rand_seed;
     int32_t min_hiders, max_hiders, min_seekers, max_seekers;
     int32_t num_pbt_policies;
-    int32_t enable_batch_renderer;   /* accepted; rgb/depth tensors are allocated, never rendered */
+    int32_t enable_batch_renderer;   /* rgb/depth tensors; rendered by hs_render / under HS_FLAG_EXT_RENDER */
     int32_t batch_render_width, batch_render_height;
     int32_t world_offset;         /* global index of local world 0 (RNG keys use global ids) */
 } hs_config;
@@ -144,6 +149,14 @@ int32_t hs_step_end(hs_sim *sim);
 /* Manager::gpuJAXStep / CUDAImpl::gpuStreamStep (src/mgr.cpp:379-398, 1006-1022): enqueue one step on a
  * caller-supplied hipStream_t (passed as void*) without synchronising. */
 int32_t hs_step_async(hs_sim *sim, void *hip_stream);
+
+/* Render every agent's view of the current state into the depth / rgb exports (Manager::step's
+ * renderMgr->batchRender(), src/mgr.cpp:894-901, with the camera of src/sim.cpp:1400-1403: 100 degrees vertical field
+ * of view, z-near 0.001, 0.5 above the agent's origin, looking along the agent's forward axis).  depth [N*A,H,W,1] f32
+ * = view-space depth of the closest hit (0: nothing hit / inactive agent); rgb [N*A,H,W,4] u8 = base colour of the hit
+ * object (src/mgr.cpp:621-647, textures not reproduced) x (0.3 + 0.7 Lambert term of the light of :657-659), alpha 255.
+ * Blocking.  Madrona's renderer is absent from the reference snapshot: the image is this build's own. */
+int32_t hs_render(hs_sim *sim);
 /* The 21 Manager::*Tensor() getters + policyAssignmentsTensor / episodeResultTensor
  * (src/mgr.cpp:1062-1336). */
 int32_t hs_get_tensor(hs_sim *sim, int32_t export_id, hs_tensor_desc *out);
@@ -178,6 +191,18 @@ int32_t hs_jax_init(hs_sim *sim, void *hip_stream, void **buffers);
 int32_t hs_jax_step(hs_sim *sim, void *hip_stream, void **buffers);
 int32_t hs_jax_save_checkpoints(hs_sim *sim, void *hip_stream, void **buffers);
 int32_t hs_jax_load_checkpoints(hs_sim *sim, void *hip_stream, void **buffers);
+
+/* The same four functions as XLA GPU custom-call targets — what madrona::py::JAXInterface::buildEntry
+ * (src/bindings.cpp:97-118) registers with XLA: `void target(stream, buffers, opaque, opaque_len)`, the original
+ * status-less custom-call ABI; XLA passes its hipStream_t, the operand and result device buffers in call order (the
+ * orders above) and the descriptor the Python side attached — the 8 bytes of the hs_sim* handle.  A failure cannot be
+ * returned through this ABI: it is kept, hs_xla_last_status(clear) reports it, and the next blocking call on the
+ * handle returns HS_ERR_HIP.  `sim.jax()` wraps the four addresses in PyCapsules named "xla._CUSTOM_CALL_TARGET". */
+void hs_xla_init(void *hip_stream, void **buffers, const char *opaque, size_t opaque_len);
+void hs_xla_step(void *hip_stream, void **buffers, const char *opaque, size_t opaque_len);
+void hs_xla_save_checkpoints(void *hip_stream, void **buffers, const char *opaque, size_t opaque_len);
+void hs_xla_load_checkpoints(void *hip_stream, void **buffers, const char *opaque, size_t opaque_len);
+int32_t hs_xla_last_status(int32_t clear);
 
 /* Manager::trainInterface (src/mgr.cpp:1338-1375): the names and roles under which `sim.jax()` hands the exported
  * tensors to the learner, in the reference's order (which is also the buffer order of hs_jax_step).  `export_id` is

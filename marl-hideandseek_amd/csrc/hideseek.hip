@@ -7,11 +7,13 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <atomic>
 
 #include "../../include/hideseek.h"
 #include "hs_state.h"
 #include "hs_k_reset.h"
 #include "hs_k_observe.h"
+#include "hs_k_render.h"
 #include "hs_k_physics.h"
 #include "hs_k_balance.h"
 #include "hs_solver.h"
@@ -67,6 +69,7 @@ struct hs_sim {
     bool step_open = false;                // hs_step_begin without its hs_step_end
     int *host_flag = nullptr;              // pinned, device-visible: set by a kernel when it bumps S.status (rare)
     int status_cache[4] = {0, 0, 0, 0};    // last copy of S.status
+    volatile int32_t async_error = 0;      // a failed XLA custom call on this handle (hs_xla_*: the ABI has no status channel)
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -88,10 +91,39 @@ void set_desc(hs_sim *s, int id, void *ptr, int dtype, std::initializer_list<int
     for (; i < 4; ++i) d.dims[i] = 1;
 }
 
+// The renderer outputs (Manager::depthTensor / rgbTensor, src/mgr.cpp:1241-1263): allocated on first need, zero-filled.
+int ensure_render_buffers(hs_sim *s) {
+    if (s->exports[HS_EXPORT_RGB].ptr && s->exports[HS_EXPORT_DEPTH].ptr) return HS_OK;
+    const int64_t r = (int64_t)s->S.N * s->A;
+    const int64_t H = s->cfg.batch_render_height > 0 ? s->cfg.batch_render_height : 64;
+    const int64_t Wd = s->cfg.batch_render_width > 0 ? s->cfg.batch_render_width : 64;
+    int rc;
+    if (!s->exports[HS_EXPORT_RGB].ptr) {
+        uint8_t *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd * 4))) != HS_OK) return rc;
+        set_desc(s, HS_EXPORT_RGB, p, HS_DTYPE_U8, {r, H, Wd, 4});
+    }
+    if (!s->exports[HS_EXPORT_DEPTH].ptr) {
+        float *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd))) != HS_OK) return rc;
+        set_desc(s, HS_EXPORT_DEPTH, p, HS_DTYPE_F32, {r, H, Wd, 1});
+    }
+    return HS_OK;
+}
+// k_render over every view (hs_k_render.h); the buffers exist (ensure_render_buffers).
+void launch_render(hs_sim *s, hipStream_t strm) {
+    const hs_tensor_desc &d = s->exports[HS_EXPORT_DEPTH];
+    const int nslots = (s->S.N + hs::kTile - 1) / hs::kTile * hs::kTile;
+    hipLaunchKernelGGL(hs::k_render, dim3(nslots * s->A), dim3(hs::kRenderThreads), 0, strm, s->S, (float *)d.ptr,
+                       (unsigned *)s->exports[HS_EXPORT_RGB].ptr, (int)d.dims[2], (int)d.dims[1]);
+}
+
 void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
     hs::SimState S = s->S;
     S.stepPar = step_par;
     if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
+    struct RenderAfter {        // HS_FLAG_EXT_RENDER: the agent views are part of every step's observations
+        hs_sim *s; hipStream_t strm;
+        ~RenderAfter() { if ((s->S.flags & hs::FLAG_EXT_RENDER) && s->exports[HS_EXPORT_DEPTH].ptr) launch_render(s, strm); }
+    } render_after{s, strm};
     // one workgroup per world; the grid covers whole groups of 8 octets (k_observe's block -> world mapping)
     const int N = ((S.N + hs::kTile - 1) / hs::kTile + 7) / 8 * 64;
     const int nt = hs::obs_threads(s->A);                          // a lane per ray (hs_k_observe.h)
@@ -229,6 +261,10 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false
 // Device-side conditions (include/hideseek.h hs_device_status).  The kernels bump S.status and raise the pinned
 // host flag only when something happened, so the check after a step is one host-memory read.
 int poll_status(hs_sim *s) {
+    if (s->async_error) {
+        const int32_t e = s->async_error; s->async_error = 0;
+        return fail(HS_ERR_HIP, "an XLA custom call on this simulator failed earlier with status " + std::to_string(e));
+    }
     if (!s->host_flag || !*(volatile int *)s->host_flag) return HS_OK;
     HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
     if (s->status_cache[2] != 0)
@@ -384,6 +420,12 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     // raw bytes, as the reference exports them (mgr.cpp:1209-1227)
     set_desc(s, HS_EXPORT_CHECKPOINT_CONTROL, S.xCkptCtrl, HS_DTYPE_U8, {n, (int64_t)sizeof(int32_t)});
     set_desc(s, HS_EXPORT_CHECKPOINT, S.xCkpt, HS_DTYPE_U8, {n, (int64_t)sizeof(hs_checkpoint)});
+    if ((S.flags & hs::FLAG_EXT_RENDER) && cfg->enable_batch_renderer) {      // rendered by every init / step
+        const int rc = ensure_render_buffers(s);
+        if (rc != HS_OK) { hs_destroy(s); return rc; }
+    } else {
+        s->S.flags &= ~(uint32_t)hs::FLAG_EXT_RENDER;                         // (the flag needs the renderer switched on)
+    }
     *out = s;
     return HS_OK;
 }
@@ -480,23 +522,27 @@ int32_t hs_get_tensor(hs_sim *s, int32_t id, hs_tensor_desc *out) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     if (id < 0 || id >= HS_NUM_EXPORTS) return fail(HS_ERR_INVALID_ARG, "export id out of range");
     if (!s->exports[id].ptr) {
-        // renderer outputs are allocated on first request and never written
+        // renderer outputs are allocated on first request; written only by hs_render / under HS_FLAG_EXT_RENDER
+        if (id != HS_EXPORT_RGB && id != HS_EXPORT_DEPTH) return fail(HS_ERR_INVALID_ARG, "export not available");
         HS_HIP(hipSetDevice(s->cfg.gpu_id));
-        const int64_t n = s->S.N, r = (int64_t)s->S.N * s->A;
-        const int64_t H = s->cfg.batch_render_height > 0 ? s->cfg.batch_render_height : 64;
-        const int64_t Wd = s->cfg.batch_render_width > 0 ? s->cfg.batch_render_width : 64;
-        int rc;
-        if (id == HS_EXPORT_RGB) {
-            uint8_t *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd * 4))) != HS_OK) return rc;
-            set_desc(s, id, p, HS_DTYPE_U8, {r, H, Wd, 4});
-        } else if (id == HS_EXPORT_DEPTH) {
-            float *p; if ((rc = s->dalloc(&p, (size_t)(r * H * Wd))) != HS_OK) return rc;
-            set_desc(s, id, p, HS_DTYPE_F32, {r, H, Wd, 1});
-        } else {
-            return fail(HS_ERR_INVALID_ARG, "export not available");
-        }
+        const int rc = ensure_render_buffers(s);
+        if (rc != HS_OK) return rc;
     }
     *out = s->exports[id];
+    return HS_OK;
+}
+
+int32_t hs_render(hs_sim *s) {
+    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
+    if (!s->initialised) return fail(HS_ERR_INVALID_ARG, "hs_render before hs_init");
+    if (s->step_open) return fail(HS_ERR_INVALID_ARG, "hs_render inside an open step");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    int rc = ensure_render_buffers(s);
+    if (rc == HS_OK) rc = order_after_default_stream(s);
+    if (rc != HS_OK) return rc;
+    launch_render(s, s->stream);
+    HS_HIP(hipGetLastError());
+    HS_HIP(hipStreamSynchronize(s->stream));
     return HS_OK;
 }
 
@@ -640,6 +686,27 @@ int32_t hs_jax_load_checkpoints(hs_sim *s, void *hip_stream, void **buffers) {
     if (rc == HS_OK) rc = copy_out_observations(s, strm, &buffers);
     return rc;
 }
+
+// ---- XLA custom-call targets (the original, status-less GPU custom-call ABI) ----
+// What madrona::py::JAXInterface registers with XLA for the four Manager functions above (src/bindings.cpp:97-118):
+// XLA calls target(stream, buffers, opaque, opaque_len) from its own stream-executor thread; `opaque` is the
+// descriptor the Python side attached to the call — here the 8 bytes of the simulator handle.  The ABI has no status
+// channel: a failure is kept (hs_xla_last_status, hs_last_error on the calling thread is not the user's thread) and
+// surfaces as HS_ERR_HIP from the next blocking call on the handle, like a failed asynchronous step.
+namespace {
+std::atomic<int32_t> g_xla_status{HS_OK};
+void xla_call(int32_t (*FN)(hs_sim *, void *, void **), void *stream, void **buffers, const char *opaque, size_t opaque_len) {
+    hs_sim *s = nullptr;
+    if (opaque && opaque_len == sizeof(s)) memcpy(&s, opaque, sizeof(s));
+    const int32_t rc = s ? FN(s, stream, buffers) : (int32_t)HS_ERR_INVALID_ARG;
+    if (rc != HS_OK) { g_xla_status.store(rc); if (s) s->async_error = rc; }
+}
+}  // namespace
+void hs_xla_init(void *stream, void **buffers, const char *opaque, size_t opaque_len) { xla_call(hs_jax_init, stream, buffers, opaque, opaque_len); }
+void hs_xla_step(void *stream, void **buffers, const char *opaque, size_t opaque_len) { xla_call(hs_jax_step, stream, buffers, opaque, opaque_len); }
+void hs_xla_save_checkpoints(void *stream, void **buffers, const char *opaque, size_t opaque_len) { xla_call(hs_jax_save_checkpoints, stream, buffers, opaque, opaque_len); }
+void hs_xla_load_checkpoints(void *stream, void **buffers, const char *opaque, size_t opaque_len) { xla_call(hs_jax_load_checkpoints, stream, buffers, opaque, opaque_len); }
+int32_t hs_xla_last_status(int32_t clear) { return clear ? g_xla_status.exchange(HS_OK) : g_xla_status.load(); }
 
 // Development aid (HS_PHASE_TIMING builds): accumulated wall-clock ticks per phase per workgroup of k_physics.
 int32_t hs_debug_phase_ticks(hs_sim *s, int64_t *out, int32_t max_groups) {

@@ -52,7 +52,7 @@ enum : int { OWNER_NONE = 0, OWNER_SEEKER = 1, OWNER_HIDER = 2, OWNER_UNOWNABLE 
 enum : int { RESP_DYNAMIC = 0, RESP_KINEMATIC = 1, RESP_STATIC = 2 };
 enum : int { AGENT_SEEKER = 0, AGENT_HIDER = 1 };
 enum : uint32_t { FLAG_USE_FIXED_WORLD = 1, FLAG_IGNORE_EPISODE_LENGTH = 2, FLAG_RANDOM_FLIP_TEAMS = 4,
-                  FLAG_ZERO_AGENT_VELOCITY = 8, FLAG_EXT_SKIP_OBSERVATIONS = 1u << 16 };
+                  FLAG_ZERO_AGENT_VELOCITY = 8, FLAG_EXT_SKIP_OBSERVATIONS = 1u << 16, FLAG_EXT_RENDER = 1u << 17 };
 
 // body meta word: (objType+1) | response<<8 | owner<<16 ; 0 == empty slot
 HSD int meta_pack(int obj, int resp, int owner) { return (obj + 1) | (resp << 8) | (owner << 16); }

@@ -35,6 +35,8 @@ class SimFlags(enum.IntFlag):
     ZeroAgentVelocity = 1 << 3
     # build-side extension (include/hideseek.h): skip the observation nodes
     ExtSkipObservations = 1 << 16
+    # build-side extension: render the agent views (depth / rgb) in every init / step when enable_batch_renderer is set
+    ExtRender = 1 << 17
 
 
 # ExportID (src/sim.hpp:45-68) + renderer outputs
@@ -112,6 +114,11 @@ class HideAndSeekSimulator:
 
     def step(self):
         _check(self._L.hs_step(self._h))
+
+    def render(self):
+        """Render every agent's view of the current state into depth_tensor() / rgb_tensor() (hs_render;
+        Manager::step's batchRender(), src/mgr.cpp:894-901).  Per step instead: SimFlags.ExtRender."""
+        _check(self._L.hs_render(self._h))
 
     def step_begin(self):
         """Enqueue one step on this handle's own stream and return (hs_step_begin); pair with step_end()."""
@@ -219,19 +226,66 @@ class HideAndSeekSimulator:
             out.setdefault(role, {})[name] = getattr(self, getter)() if getter else None
         return out
 
-    def jax(self, jax_gpu):
-        """bindings.cpp:97-118 (JAXInterface::buildEntry).  The interface table and the four stream functions an
-        XLA custom call would invoke exist natively (hs_train_interface, hs_jax_init / step / save_checkpoints /
-        load_checkpoints = stream_init / stream_step / ...); registering them with XLA needs jaxlib, which is not
-        on the target.  The table is built first and travels on the exception."""
+    # ---- XLA custom calls (bindings.cpp:97-118: madrona::py::JAXInterface::buildEntry) ----
+    def xla_opaque(self):
+        """The descriptor an XLA custom call of this simulator carries: the 8 bytes of the native handle."""
+        return int(self._h.value).to_bytes(8, "little")
+
+    def xla_custom_call_targets(self):
+        """{'init' | 'step' | 'save_ckpts' | 'load_ckpts': PyCapsule("xla._CUSTOM_CALL_TARGET")} around the native
+        hs_xla_* functions (include/hideseek.h) — what xla_client.register_custom_call_target(name, capsule,
+        platform="ROCM") takes."""
+        new = C.pythonapi.PyCapsule_New
+        new.restype = C.py_object
+        new.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        return {k: new(C.cast(getattr(self._L, sym), C.c_void_p).value, b"xla._CUSTOM_CALL_TARGET", None)
+                for k, sym in _native.XLA_TARGETS.items()}
+
+    def xla_call_signatures(self):
+        """Operand and result lists (name, shape, dtype) of the four custom calls, in buffer order
+        (mgr.cpp:168-201, 362-436) — what a lowering rule needs besides the target and the opaque."""
         iface = self.train_interface()
-        err = NotImplementedError(
-            "sim.jax(): the XLA custom-call registration needs jaxlib, which is not on the target (SURVEY §7 H8). "
-            "The interface table (sim.train_interface(), attached to this exception as .train_interface) and the "
-            "stream functions it would register (stream_init / stream_step / stream_save_checkpoints / "
-            "stream_load_checkpoints) exist natively; Tensor.to_jax() hands the buffers over through DLPack.")
-        err.train_interface = iface
-        raise err
+
+        def sig(t):
+            return (tuple(t.shape), t.dtype)
+        obs = [(n, *sig(t)) for n, t in iface["observations"].items()]
+        act = [("actions", *sig(self.action_tensor())), ("resets", *sig(self.reset_tensor())),
+               ("policy_assignments", *sig(self.policy_assignments_tensor()))]
+        out = [("rewards", *sig(self.reward_tensor())), ("dones", *sig(self.done_tensor())),
+               ("episode_results", *sig(self.episode_result_tensor()))]
+        ck = [("ckpt_ctrl", *sig(self.ckpt_ctrl_tensor())), ("ckpts", *sig(self.ckpt_tensor()))]
+        return {"init": {"operands": [], "results": obs},
+                "step": {"operands": act, "results": obs + out},
+                "save_ckpts": {"operands": ck[:1], "results": ck[1:]},
+                "load_ckpts": {"operands": ck, "results": obs}}
+
+    def jax(self, jax_gpu):
+        """bindings.cpp:97-118 (JAXInterface::buildEntry).  Everything XLA needs exists natively: the interface table
+        (hs_train_interface), the four custom-call targets in XLA's own ABI (hs_xla_init / step / save_checkpoints /
+        load_checkpoints — xla_custom_call_targets()), their descriptor (xla_opaque()) and their operand / result
+        lists (xla_call_signatures()).  With jaxlib importable the targets are registered for the ROCm platform and
+        the bundle is returned; without it (this image and the target: SURVEY §7 H8) the same bundle travels on the
+        NotImplementedError, because the JAX-side lowering rules cannot be exercised here."""
+        if not jax_gpu:
+            raise NotImplementedError("sim.jax(jax_gpu=False): there is no CPU execution path (DESIGN.md §1)")
+        bundle = {"train_interface": self.train_interface(), "targets": self.xla_custom_call_targets(),
+                  "opaque": self.xla_opaque(), "signatures": self.xla_call_signatures(),
+                  "target_names": {k: f"gpu_hideseek_{k}_{id(self):x}" for k in _native.XLA_TARGETS}}
+        try:
+            from jax.lib import xla_client
+        except ImportError:
+            err = NotImplementedError(
+                "sim.jax(): jaxlib is not importable (SURVEY §7 H8), so the XLA custom-call targets cannot be "
+                "registered here. They exist natively (hs_xla_*); the bundle a registration needs — capsules, "
+                "opaque descriptor, operand / result signatures, interface table — is attached as .xla and "
+                ".train_interface; stream_init / stream_step / ... call the same functions directly, and "
+                "Tensor.to_jax() hands buffers over through DLPack.")
+            err.train_interface = bundle["train_interface"]
+            err.xla = bundle
+            raise err
+        for k, cap in bundle["targets"].items():
+            xla_client.register_custom_call_target(bundle["target_names"][k], cap, platform="ROCM")
+        return bundle
 
     def device_status(self):
         """hs_get_device_status: sticky device-side conditions (dropped broadphase pairs) and whether graphs are in use."""

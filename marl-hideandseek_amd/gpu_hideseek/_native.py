@@ -30,6 +30,10 @@ class HsDeviceStatus(C.Structure):
                 ("graphs_in_use", C.c_int32), ("sched_error", C.c_int32)]
 
 
+# XLA custom-call targets (include/hideseek.h hs_xla_*): the key `sim.jax()` files each one under -> native symbol
+XLA_TARGETS = {"init": "hs_xla_init", "step": "hs_xla_step", "save_ckpts": "hs_xla_save_checkpoints",
+               "load_ckpts": "hs_xla_load_checkpoints"}
+
 _lib = None
 
 
@@ -53,7 +57,7 @@ def load():
     L.hs_create.restype = C.c_int32
     L.hs_destroy.argtypes = [C.c_void_p]
     L.hs_destroy.restype = None
-    for n in ("hs_init", "hs_step", "hs_step_begin", "hs_step_end", "hs_save_checkpoints", "hs_load_checkpoints"):
+    for n in ("hs_init", "hs_step", "hs_step_begin", "hs_step_end", "hs_save_checkpoints", "hs_load_checkpoints", "hs_render"):
         getattr(L, n).argtypes = [C.c_void_p]
         getattr(L, n).restype = C.c_int32
     for n in ("hs_save_checkpoint", "hs_load_checkpoint", "hs_set_overlap", "hs_debug_inject_sched_error"):
@@ -62,6 +66,11 @@ def load():
     for n in ("hs_jax_init", "hs_jax_step", "hs_jax_save_checkpoints", "hs_jax_load_checkpoints"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         getattr(L, n).restype = C.c_int32
+    for n in XLA_TARGETS.values():
+        getattr(L, n).argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        getattr(L, n).restype = None
+    L.hs_xla_last_status.argtypes = [C.c_int32]
+    L.hs_xla_last_status.restype = C.c_int32
     L.hs_step_async.argtypes = [C.c_void_p, C.c_void_p]
     L.hs_step_async.restype = C.c_int32
     L.hs_get_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(HsTensorDesc)]

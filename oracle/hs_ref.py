@@ -48,6 +48,8 @@ def lib():
         L.hsref_agents_per_world.restype = C.c_int32
         L.hsref_tensor.argtypes = [C.c_void_p, C.c_int32]
         L.hsref_tensor.restype = C.c_void_p
+        L.hsref_render.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.hsref_render.restype = None
         L.hsref_dump_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hsref_dump_walls.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hsref_threefry.argtypes = [C.c_uint32] * 4 + [C.c_void_p]
@@ -138,6 +140,13 @@ class RefSim:
     def load_checkpoints(self):
         """LoadCheckpoints task graph (sim.cpp:1324-1333): restore triggered worlds, refresh observations."""
         lib().hsref_load_checkpoints(self._h)
+
+    def render(self, width=64, height=64):
+        """Agent views of the current state (hs_ref_render.hpp): depth [N*A,H,W,1] f32, rgb [N*A,H,W,4] u8."""
+        depth = np.zeros((self.N * self.A, height, width, 1), np.float32)
+        rgb = np.zeros((self.N * self.A, height, width, 4), np.uint8)
+        lib().hsref_render(self._h, width, height, depth.ctypes.data, rgb.ctypes.data)
+        return depth, rgb
 
     def bodies(self):
         b = np.zeros((self.N, 17, 13), np.float32)

@@ -3,6 +3,7 @@
 // restatement through ctypes.  Export ids mirror ExportID (src/sim.hpp:45-68).
 #include "hs_ref_sim.hpp"
 #include "hs_ref_ckpt.hpp"
+#include "hs_ref_render.hpp"
 
 using namespace hsref;
 
@@ -34,6 +35,9 @@ void hsref_step(void *p) { ((Sim *)p)->step(); }
 int32_t hsref_agents_per_world(void *p) { return ((Sim *)p)->A; }
 void hsref_save_checkpoints(void *p) { sim_save_checkpoints(*(Sim *)p); }
 void hsref_load_checkpoints(void *p) { sim_load_checkpoints(*(Sim *)p); }
+
+// agent views of the current state: depth [N*A][H][W] f32, rgba [N*A][H][W][4] u8 (hs_ref_render.hpp)
+void hsref_render(void *p, int32_t W, int32_t H, float *depth, uint8_t *rgba) { render_views(*(Sim *)p, W, H, depth, (uint32_t *)rgba); }
 
 // ExportID order: Reset, PrepCounter, Action, SelfObs, SelfType, SelfMask, AgentObsData,
 // BoxObsData, RampObsData, AgentVisMasks, BoxVisMasks, RampVisMasks, Lidar, Seed, Reward, Done,

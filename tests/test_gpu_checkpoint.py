@@ -164,6 +164,79 @@ def test_stream_entry_points_match_blocking_api(oracle):
         b.stream_step(strm.cuda_stream, obs)
 
 
+def test_xla_custom_call_targets_match_blocking_api(oracle):
+    """The four hs_xla_* targets, called the way XLA calls a GPU custom call — target(stream, buffers, opaque,
+    opaque_len) with the address taken out of the "xla._CUSTOM_CALL_TARGET" capsule `sim.jax()` would register and
+    the handle as the opaque descriptor — give the blocking API's results; a call without a valid descriptor is
+    recorded (the ABI cannot return it) and a failure on a handle surfaces at its next blocking call."""
+    import ctypes as C
+    import torch
+    import gpu_hideseek
+    kw = dict(exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=40, sim_flags=13, rand_seed=5,
+              min_hiders=3, max_hiders=3, min_seekers=3, max_seekers=3, num_pbt_policies=1)
+    a = gpu_hideseek.HideAndSeekSimulator(**kw)
+    b = gpu_hideseek.HideAndSeekSimulator(**kw)
+    with pytest.raises(NotImplementedError) as ei:          # jaxlib is not importable: the bundle travels on the error
+        b.jax(True)
+    xla = ei.value.xla
+    assert set(xla["targets"]) == {"init", "step", "save_ckpts", "load_ckpts"} and len(xla["opaque"]) == 8
+    get_ptr = C.pythonapi.PyCapsule_GetPointer
+    get_ptr.restype = C.c_void_p
+    get_ptr.argtypes = [C.py_object, C.c_char_p]
+    proto = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t)
+    fn = {k: proto(get_ptr(cap, b"xla._CUSTOM_CALL_TARGET")) for k, cap in xla["targets"].items()}
+
+    def call(name, stream, bufs, opaque=None):
+        arr = (C.c_void_p * len(bufs))(*[int(t.data_ptr()) for t in bufs])
+        op = xla["opaque"] if opaque is None else opaque
+        fn[name](C.c_void_p(stream.cuda_stream), arr, op, len(op))
+
+    sig = xla["signatures"]
+    dt = {"int32": torch.int32, "float32": torch.float32, "uint8": torch.uint8}
+    mk = lambda lst: [torch.zeros(shape, dtype=dt[d], device="cuda") for _n, shape, d in lst]
+    obs = mk(sig["init"]["results"])
+    obs_names = [n for n, _s, _d in sig["init"]["results"]]
+    iface_a = a.train_interface()["observations"]
+    strm = torch.cuda.Stream()
+    a.init()
+    call("init", strm, obs)
+    for n, o in zip(obs_names, obs):
+        assert torch.equal(o.view(torch.int32), iface_a[n].to_torch().view(torch.int32)), n
+    ins = mk(sig["step"]["operands"]); tail = mk(sig["step"]["results"][len(obs):])
+    rng = np.random.default_rng(2)
+    for t in range(5):
+        act = np.concatenate([rng.integers(0, 5, size=(240, 3)), rng.integers(0, 2, size=(240, 2))], axis=1).astype(np.int32)
+        ins[0].copy_(torch.from_numpy(act).cuda())
+        a.action_tensor().to_torch().copy_(ins[0])
+        a.step()
+        strm.wait_stream(torch.cuda.current_stream())
+        call("step", strm, ins + obs + tail)
+        strm.synchronize()
+        for n, o in zip(obs_names, obs):
+            assert torch.equal(o.view(torch.int32), iface_a[n].to_torch().view(torch.int32)), (t, n)
+        assert torch.equal(tail[0].view(torch.int32), a.reward_tensor().to_torch().view(torch.int32))
+        assert torch.equal(tail[1], a.done_tensor().to_torch())
+    ck = mk(sig["save_ckpts"]["operands"]) + mk(sig["save_ckpts"]["results"])
+    ck[0].fill_(1)
+    call("save_ckpts", strm, ck); strm.synchronize()
+    a.ckpt_ctrl_tensor().to_torch().view(torch.int32)[:] = 1
+    a.save_checkpoints()
+    assert torch.equal(ck[1], a.ckpt_tensor().to_torch())
+    for s in (a, b):
+        s.step()
+    call("load_ckpts", strm, ck + obs); strm.synchronize()
+    a.ckpt_ctrl_tensor().to_torch().view(torch.int32)[:] = 1
+    a.load_checkpoints()
+    for n, o in zip(obs_names, obs):
+        assert torch.equal(o.view(torch.int32), iface_a[n].to_torch().view(torch.int32)), n
+    assert np.array_equal(bits(a.debug_bodies()[0]), bits(b.debug_bodies()[0]))
+    # no status channel in the ABI: failures are kept
+    L = b._L
+    assert L.hs_xla_last_status(1) == 0
+    call("step", strm, ins + obs + tail, opaque=b"\0" * 4)           # malformed descriptor
+    assert L.hs_xla_last_status(1) == 1 and L.hs_xla_last_status(0) == 0
+
+
 def test_replay_log_round_trip(oracle, tmp_path):
     """The replay-log format of scripts/jax_infer.py:125 / src/viewer.cpp:13-26,185-215: record a run, play it back
     in a fresh simulator, and get the recorded body state and observations at every step."""

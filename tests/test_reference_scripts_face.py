@@ -151,6 +151,23 @@ def test_train_interface_names_roles_and_order(hideseek_lib):
     assert [by[n][1][:-len("_tensor")] for n in OBS_NAMES] == OBS
 
 
+def test_xla_targets_are_exported_in_xlas_abi(hideseek_lib):
+    """bindings.cpp:97-118: the four custom-call targets exist as C symbols with XLA's signature and the Python face
+    names them as the reference's jax() dict does ('save_ckpts' is read at scripts/jax_infer.py:137)."""
+    import ctypes as C
+    from gpu_hideseek import _native
+    assert set(_native.XLA_TARGETS) == {"init", "step", "save_ckpts", "load_ckpts"}
+    L = C.CDLL(hideseek_lib)
+    for sym in _native.XLA_TARGETS.values():
+        assert hasattr(L, sym)
+    L.hs_xla_last_status.restype = C.c_int32
+    # a call without a descriptor touches no GPU: it is recorded as an invalid-argument failure
+    L.hs_xla_step.restype = None
+    L.hs_xla_step.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.hs_xla_step(None, None, None, 0)
+    assert L.hs_xla_last_status(1) == 1 and L.hs_xla_last_status(0) == 0
+
+
 def test_shard_index_arithmetic():
     from gpu_hideseek.sharded import locate, shard_ranges
     r = shard_ranges(131072, 8)
