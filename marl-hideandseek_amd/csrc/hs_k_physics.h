@@ -79,33 +79,25 @@ static_assert(offsetof(OctRes, u.sat.items) >= offsetof(OctRes, u.det.wall), "it
 
 // ---- candidate pairs and where their contact manifolds live ----
 // A manifold produced by the LAST contact-generation round of a substep (nearly always the only one) stays in LDS:
-// lane i of that round writes it over its own column of the clip buffers (words k * 32 + i: the lane's own clipping
-// scratch, dead by then — no other lane ever touches that column), where the solver phases of the substep read it.
-// Columns 0..30 are slots; location 31 = the manifold is in the global workspace (S.wsDD / S.wsSC): earlier rounds of
-// a substep with more than 32 colliding pairs, the 32nd lane of the last round, extra planes of the debug levels.
+// when every lane of that round is done with its clipping scratch, lane i writes its manifold into slot i of the clip
+// buffers (36 consecutive words, moved 16 bytes at a time), where the solver phases of the substep read it.
+// Slots 0..30; location 31 = the manifold is in the global workspace (S.wsDD / S.wsSC): earlier rounds of a substep
+// with more than 32 colliding pairs, the 32nd lane of the last round, extra planes of the debug levels.
 constexpr int kLocGlobal = 31;
 HSD int pair_a(int p) { return p & 31; }
 HSD int pair_b(int p) { return (p >> 5) & 63; }
 HSD int pair_loc(int p) { return (p >> 11) & 31; }
 HSD int pair_pack(int a, int b) { return a | (b << 5) | (kLocGlobal << 11); }
 static_assert(kNumDSlots <= 32 && kMaxWalls + kMaxPlanes <= 64, "pair encoding");
-static_assert(sizeof(ManDD) / 4 * kClipLanes <= kClipWords, "a manifold fits the lane's clip column");
-template <typename M> HSD void man_lds_store(float *clip, int slot, const M &m) {
-    int w[sizeof(M) / 4];
-    __builtin_memcpy(w, &m, sizeof(M));
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(M) / 4); ++k) ((int *)clip)[k * kClipLanes + slot] = w[k];
-}
+static_assert(sizeof(ManDD) / 4 * kLocGlobal <= kClipWords && sizeof(ManDD) % 16 == 0 && sizeof(ManS) % 16 == 0, "manifold slots in the clip buffers");
+constexpr int kManWords = sizeof(ManDD) / 4;          // slot stride (a ManS record uses the first 28 words)
 template <typename M> HSD void man_lds_load(const float *clip, int slot, M &m) {
-    int w[sizeof(M) / 4];
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(M) / 4); ++k) w[k] = ((const int *)clip)[k * kClipLanes + slot];
-    __builtin_memcpy(&m, w, sizeof(M));
+    m = *reinterpret_cast<const M *>(clip + slot * kManWords);          // 16-byte reads
 }
 // accumulated normal multipliers of a manifold in LDS: the last 4 words of either record
 template <typename M> HSD void man_lds_set_lam(float *clip, int slot, int j, float v) {
     static_assert(offsetof(M, lam) == sizeof(M) - 16, "lam is the record's tail");
-    clip[(sizeof(M) / 4 - 4 + j) * kClipLanes + slot] = v;
+    clip[slot * kManWords + (sizeof(M) / 4 - 4 + j)] = v;
 }
 
 // ---- accessors of the resident columns ----
@@ -386,6 +378,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
     const int lane = threadIdx.x & 63;
     const bool toLds = last && lane < kLocGlobal;
     bool wroteGlobal = false;
+    int mw[kManWords]; int mkind = 0, mkk = 0, mg = 0, mpair = 0;      // the manifold for LDS: 1 body-body, 2 body-static
     if (lane < npend) {
         const int item = R.u.sat.pend[0][lane];
         AxisResult res;
@@ -418,7 +411,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
                     st3(m.rB[j], on ? qrot(qbi, raw.pB[j] - pb) : V3{0.f, 0.f, 0.f});
                     m.lam[j] = 0.f;
                 }
-                if (toLds) { man_lds_store(R.u.sat.clip, lane, m); R.ddPair[kk][g] = (unsigned short)((pair & 0x7ff) | (lane << 11)); }
+                if (toLds) { __builtin_memcpy(mw, &m, sizeof(m)); mkind = 1; mkk = kk; mg = g; mpair = pair; }
                 else { ((ManDD *)S.wsDD + (size_t)w * kMaxDDCand)[kk] = m; wroteGlobal = true; }
                 atomicOr(&R.ddAcc[g], 1u << kk);
             } else {
@@ -431,10 +424,24 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
                     st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
                     m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                 }
-                if (toLds) { man_lds_store(R.u.sat.clip, lane, m); R.scPair[kk][g] = (unsigned short)((pair & 0x7ff) | (lane << 11)); }
+                if (toLds) { __builtin_memcpy(mw, &m, sizeof(m)); mkind = 2; mkk = kk; mg = g; mpair = pair; }
                 else { ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m; wroteGlobal = true; }
                 atomicOr(&R.scAcc[g], 1u << kk);
             }
+        }
+    }
+    // every lane is done with its clipping scratch: the slots may overwrite it
+    wave_sync(); __builtin_amdgcn_wave_barrier();
+    if (mkind != 0) {
+        int4 *dst = reinterpret_cast<int4 *>(R.u.sat.clip + lane * kManWords);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(ManS) / 16); ++k) dst[k] = int4{mw[4 * k], mw[4 * k + 1], mw[4 * k + 2], mw[4 * k + 3]};
+        if (mkind == 1) {
+#pragma unroll
+            for (int k = (int)(sizeof(ManS) / 16); k < (int)(sizeof(ManDD) / 16); ++k) dst[k] = int4{mw[4 * k], mw[4 * k + 1], mw[4 * k + 2], mw[4 * k + 3]};
+            R.ddPair[mkk][mg] = (unsigned short)((mpair & 0x7ff) | (lane << 11));
+        } else {
+            R.scPair[mkk][mg] = (unsigned short)((mpair & 0x7ff) | (lane << 11));
         }
     }
     wave_sync();
