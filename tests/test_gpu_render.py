@@ -91,3 +91,16 @@ def test_flag_needs_the_renderer_and_default_stays_dummy(oracle):
     assert not sim.rgb_tensor().to_torch().any()
     sim.render()
     assert_views_equal(sim, ref, 64, 64, "on request")
+
+
+def test_view_culls_lose_no_hit_over_many_worlds(oracle):
+    """k_render leaves out walls and hulls that cannot be in a view and skips walls beyond the depth at which a wave's
+    rays leave the walls' height range; the oracle tests every ray against everything.  1 536 views of 384 different
+    levels at two moments of the episode, every pixel equal."""
+    W, H = 40, 24
+    sim, ref, gt = make(oracle, 384, 0, 77, (2, 2), (2, 2), W, H)
+    sim.render()
+    assert_views_equal(sim, ref, W, H, "init")
+    drive(sim, ref, gt, 130, "bench", seed=5, check_every=130)
+    sim.render()
+    assert_views_equal(sim, ref, W, H, "step 130")
