@@ -1,10 +1,11 @@
 // Agent-view depth / RGB: the batch renderer outputs of Manager::depthTensor / rgbTensor (src/mgr.cpp:1241-1263).
 //
 // The reference hands these to Madrona's batch renderer (engine source absent).  What first-party
-// source fixes is the camera — RenderingSystem::attachEntityToView(agent, 100 degrees vertical field of view,
-// z-near 0.001, offset 0.5 up; src/sim.cpp:1400-1403) — the base colours per object type and one directional light
-// (src/mgr.cpp:621-660).  This kernel is a ray caster over the same flat per-world geometry the lidar uses
-// (hs_rays.h trace_ray): one workgroup per view, a lane per pixel column, closest hit per pixel.
+// source fixes is the camera — RenderingSystem::attachEntityToView(agent interface, 100 degrees vertical field of
+// view, z-near 0.001, offset 0.5 up; src/sim.cpp:1400-1403), the interface entity taking its agent's pose in
+// updateCameraSystem (:943-954) — the base colours per object type and one directional light (src/mgr.cpp:621-660).
+// This kernel is a ray caster over the same flat per-world geometry the lidar uses (hs_rays.h): one workgroup per
+// view, a lane per pixel, closest hit per pixel.
 //   depth  view-space depth of the hit (distance along the camera's forward axis), 0 where nothing is hit
 //   rgb    base colour of the hit object x (0.3 ambient + 0.7 Lambert term of the light), alpha 255; black sky
 // The reference's textures (floor grid, the agents' faces) are not reproduced; the seeker's red face texture is stood

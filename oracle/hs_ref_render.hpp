@@ -1,8 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hs_ref_math.hpp header).  PARITY UNPINNED.
 // CPU restatement of the agent-view depth / RGB images (Manager::depthTensor / rgbTensor, src/mgr.cpp:1241-1263).
 // Madrona's batch renderer is absent from the reference snapshot; first-party source fixes the camera
-// (RenderingSystem::attachEntityToView(agent, 100.f, 0.001f, 0.5f * math::up), src/sim.cpp:1400-1403), the base
-// colours per object type (src/mgr.cpp:621-647) and the directional light (src/mgr.cpp:657-659).  The image itself
+// (RenderingSystem::attachEntityToView(agent_iface, 100.f, 0.001f, 0.5f * math::up), src/sim.cpp:1400-1403, the
+// interface entity taking its agent's pose in updateCameraSystem, :943-954), the base colours per object type
+// (src/mgr.cpp:621-647) and the directional light (src/mgr.cpp:657-659).  The image itself
 // is this build's own definition (DESIGN.md "Engine decisions"): a ray cast per pixel through trace_ray,
 // depth = view-space depth of the closest hit (0: none), colour = base x (0.3 + 0.7 max(0, n . toLight)).
 #pragma once

@@ -18,3 +18,9 @@ HS_OVERLAP=0 HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so tim
 timeout -k 10 200 python3 tools/step_hist.py 2>&1 | grep -v amdgpu.ids > $O/step_hist.txt
 HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so timeout -k 10 200 python3 tools/phase_tail.py 16000 240 2>&1 | grep -v amdgpu.ids > $O/phase_tail.txt
 tail -3 $O/kstats.txt; cat $O/traffic_summary.txt; tail -3 $O/sq_counters.txt; cat $O/step_hist.txt
+# agent-view renderer (opt-in): time per render and rocprofv3 kernel stats of the same command
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/kstats_render
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats_render -- python3 tools/render_bench.py 16000 64 64 10 > $O/render_bench.txt 2>&1 || exit 1
+grep -v amdgpu.ids $O/render_bench.txt | tail -2
+cp $(ls gpurun_out/kstats_render/*/*kernel_stats.csv | head -1) $O/render_kernel_stats.csv
