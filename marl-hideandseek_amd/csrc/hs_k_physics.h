@@ -844,9 +844,14 @@ HSD void wall_round(const SimState &S, OctRes &R, int nwb) {
         ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kMaxSCand;
         BodyS me, none;
         rbody_load(R, g, slot, me);
+        // the body's ACCEPTED candidates in candidate order, a lane at its own pace: a trip of the loop is a whole manifold
+        // solve for the wave, so the trips are the largest number of manifolds any listed body has (mostly one), not
+        // the span of candidate positions over the lanes
+        unsigned todo = (acc >> bsc) & ((1u << asc) - 1u);
 #pragma unroll 1
-        for (int k = bsc; k < bsc + asc; ++k) {
-            if (!((acc >> k) & 1u)) continue;
+        while (todo != 0u) {
+            const int k = bsc + __ffs((int)todo) - 1;
+            todo &= todo - 1u;
             const int loc = pair_loc(R.scPair[k][g]);
             ManS m;
             if (loc != kLocGlobal) man_lds_load(R.u.sat.clip, loc, m); else m = wsSC[k];
