@@ -788,12 +788,14 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
 // body is solved by the body's own lane (registers).  The few bodies that also touch a wall would make their whole
 // round wait, so their wall manifolds are solved in a round of their own — one lane per such body, compacted over
 // the octet (wallBodies) — between the ground pass and the velocity derivation.
+struct WallLists { int nwb, nEarly; };     // listed bodies; how many of them belong to a round before the last one
 template <int ROUNDS>
-HSD int list_wall_bodies(OctRes &R, int nbodies) {
+HSD WallLists list_wall_bodies(OctRes &R, int nbodies) {
     const int L = threadIdx.x;
-    int n = 0;
+    int n = 0, nEarly = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
+        if (r == ROUNDS - 1) nEarly = n;
         const bool valid = r * 64 + L < nbodies;
         const int t = valid ? R.bodies[r * 64 + L] : 0;
         const int sci = valid ? R.scInfo[t >> 3][t & 7] : 0;
@@ -803,7 +805,7 @@ HSD int list_wall_bodies(OctRes &R, int nbodies) {
         n += __popcll(m);
     }
     wave_sync();
-    return n;
+    return {n, nEarly};
 }
 
 HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
@@ -834,8 +836,8 @@ HSD void ground_vel(OctRes &R, const BodyReg &b, int slot, int g, int meta) {
 }
 // The wall / extra-plane manifolds of the listed bodies, one lane per body, candidates in solve order.
 template <bool POS>
-HSD void wall_round(const SimState &S, OctRes &R, int nwb) {
-    for (int i = threadIdx.x; i < nwb; i += 64) {
+HSD void wall_round(const SimState &S, OctRes &R, int first, int nwb) {
+    for (int i = first + threadIdx.x; i < nwb; i += 64) {
         const int t = R.wallBodies[i];
         const int slot = t >> 3, g = t & 7;
         const int sci = R.scInfo[slot][g];
@@ -872,6 +874,66 @@ HSD void wall_round(const SimState &S, OctRes &R, int nwb) {
         }
         if (POS) rbody_store_pose(R, g, slot, me); else rbody_store_vel(R, g, slot, me);
     }
+}
+// The LAST round of bodies is rarely full (96 bodies on average: 64 + 32), and a round costs the wave the same whatever
+// the number of busy lanes.  Its idle lanes therefore take the wall / extra-plane manifolds of listed bodies that belong
+// to an EARLIER round (their ground manifold is done by then), `nMerged` of them: a lane of this round walks a list of
+// static manifolds — the ground manifold from its registers, or a listed body's accepted candidates from LDS — through
+// one and the same solve code.  What does not fit (bodies of the last round itself, more listed bodies than idle lanes)
+// is left to wall_round.  Per body the order stays ground, then its static candidates by index.
+template <bool POS>
+HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int slot, int g, int meta, int nLast, int nMerged) {
+    const int mi = (int)threadIdx.x - nLast;
+    const bool walls = mi >= 0 && mi < nMerged;
+    unsigned todo = 0u; int bsc = 0;
+    if (walls) {
+        const int t = R.wallBodies[mi];
+        slot = t >> 3; g = t & 7; meta = R.meta[slot][g];
+        const int sci = R.scInfo[slot][g];
+        bsc = sci & 0xff;
+        todo = (R.scAcc[g] >> bsc) & ((1u << (sci >> 8)) - 1u);
+    } else if (valid && meta_resp(meta) == RESP_DYNAMIC && b.np != 0) {
+        todo = 1u;
+    }
+    if (todo == 0u) return;
+    const int obj = meta_obj(meta);
+    BodyS me, none;
+    rbody_load(R, g, slot, me);
+    ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kMaxSCand;
+#pragma unroll 1
+    while (todo != 0u) {
+        const int k = bsc + __ffs((int)todo) - 1;
+        todo &= todo - 1u;
+        V3 n, rA[4]; float mu, off[4], lam[4]; int np, loc = kLocGlobal;
+        if (walls) {
+            loc = pair_loc(R.scPair[k][g]);
+            ManS m;
+            if (loc != kLocGlobal) man_lds_load(R.u.sat.clip, loc, m); else m = wsSC[k];
+            n = ld3(m.n); mu = POS ? m.muS : m.muD; np = m.np;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rA[j] = ld3(m.rA[j]); off[j] = m.offB[j]; lam[j] = m.lam[j]; }
+        } else {
+            n = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
+            mu = POS ? 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE)) : 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
+            np = b.np;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rA[j] = hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7); off[j] = b.off[j]; lam[j] = b.lam[j]; }
+        }
+        body_refresh_inertia(me);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < np) {
+                if (POS) {
+                    const float nl = lam[j] + solve_point_position<false>(me, none, n, rA[j], V3{0.f, 0.f, 0.f}, off[j], mu);
+                    if (!walls) b.lam[j] = nl;
+                    else if (loc != kLocGlobal) man_lds_set_lam<ManS>(R.u.sat.clip, loc, j, nl);
+                    else wsSC[k].lam[j] = nl;
+                } else {
+                    solve_point_velocity<false>(me, none, n, rA[j], V3{0.f, 0.f, 0.f}, lam[j], mu);
+                }
+            }
+    }
+    if (POS) rbody_store_pose(R, g, slot, me); else rbody_store_vel(R, g, slot, me);
 }
 HSD void derive_body_velocity(OctRes &R, int slot, int g, int meta) {
     if (meta_resp(meta) != RESP_DYNAMIC) return;
@@ -1121,11 +1183,14 @@ HSD void physics_step(SimState &S, OctRes &R) {
         int base = 0;
 #pragma unroll
         for (int c = 0; c < ROUNDS; ++c) {
+            // (agents first: they are the bodies that run into walls, and the wall manifolds of a body of an earlier
+            // round ride in the idle lanes of the last one — last_round)
             const int t = c * 64 + L;
-            const int slot = t >> 3, g = t & 7;
-            const bool on = slot < NS && R.meta[slot][g] != 0;
+            const int ord = t >> 3, g = t & 7;
+            const int slot = ord < S.A ? kAgentSlot0 + ord : ord - S.A;
+            const bool on = ord < NS && R.meta[slot][g] != 0;
             const unsigned long long m = __ballot(on);
-            if (on) R.bodies[base + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)t;
+            if (on) R.bodies[base + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)(slot << 3 | g);
             base += __popcll(m);
         }
         nbodies = base;
@@ -1161,11 +1226,15 @@ HSD void physics_step(SimState &S, OctRes &R) {
         HS_TICK(3)
         phase_dd<true>(S, R);
         HS_TICK(4)
-        const int nwb = list_wall_bodies<ROUNDS>(R, nbodies);
+        const WallLists wl = list_wall_bodies<ROUNDS>(R, nbodies);
+        const int nLast = max(nbodies - 64 * (ROUNDS - 1), 0);          // bodies of the last round
+        const int nMerged = min(wl.nEarly, 64 - nLast);                 // listed bodies its idle lanes take
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) ground_pos(R, br[r], slot, g, meta); }
+        for (int r = 0; r < ROUNDS - 1; ++r) { HS_BODY(r) if (valid) ground_pos(R, br[r], slot, g, meta); }
+        wave_sync();                      // (the poses of the earlier rounds, for the merged lanes)
+        { HS_BODY(ROUNDS - 1) last_round<true>(S, R, br[ROUNDS - 1], valid, slot, g, meta, nLast, nMerged); }
         wave_sync();
-        if (nwb > 0) { wall_round<true>(S, R, nwb); wave_sync(); }
+        if (wl.nwb > nMerged) { wall_round<true>(S, R, nMerged, wl.nwb); wave_sync(); }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
         if (manGlobal) mem_sync(); else wave_sync();   // (the multipliers of manifolds in the global workspace, for the velocity pass)
@@ -1173,9 +1242,11 @@ HSD void physics_step(SimState &S, OctRes &R) {
         phase_dd<false>(S, R);
         HS_TICK(6)
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) ground_vel(R, br[r], slot, g, meta); }
+        for (int r = 0; r < ROUNDS - 1; ++r) { HS_BODY(r) if (valid) ground_vel(R, br[r], slot, g, meta); }
         wave_sync();
-        if (nwb > 0) { wall_round<false>(S, R, nwb); wave_sync(); }
+        { HS_BODY(ROUNDS - 1) last_round<false>(S, R, br[ROUNDS - 1], valid, slot, g, meta, nLast, nMerged); }
+        wave_sync();
+        if (wl.nwb > nMerged) { wall_round<false>(S, R, nMerged, wl.nwb); wave_sync(); }
         if (sub + 1 < kNumSubsteps) {
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) integrate_body(R, br[r], slot, g, meta); }
