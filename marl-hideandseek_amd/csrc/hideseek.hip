@@ -355,7 +355,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
       if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
       HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
     S.stepPar = -1;
-    HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N);
+    HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N); HS_ALLOC(S.wallHist, N);
     if ((rc = s->dalloc(&S.slotHdr, NP, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }      // world id -1: empty slot
     HS_ALLOC(S.lidarSinCos, 60);
     HS_ALLOC(S.octTicks, NP / hs::kTile); HS_ALLOC(S.tickSum, 3);

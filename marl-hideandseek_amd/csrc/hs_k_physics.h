@@ -69,8 +69,12 @@ struct alignas(16) OctRes {
     unsigned int ddOrd[2][kTile];               // the accepted body-body candidates in solve order, 4 bits each (phase_dd)
     float plane0[4][kTile];                     // the ground plane nx, ny, nz, d of every world
     unsigned char bodies[kNumDSlots * kTile];   // compact list of existing bodies: slot << 3 | world
-    unsigned char wallBodies[kNumDSlots * kTile];   // bodies with a wall / extra-plane manifold in this substep
-    unsigned char actGL[kMaxAgents][kTile];     // grab / lock requests
+    union {
+        unsigned char wallBodies[kNumDSlots * kTile];   // bodies with a wall / extra-plane manifold in this substep
+        unsigned char actGL[kMaxAgents][kTile];         // grab / lock requests (phase_pre only)
+    };
+    unsigned int wallSeen[kTile];               // bit s: body slot s had a wall / extra-plane manifold (previous step's while the
+                                                // body list is built, then this step's: SimState::wallHist)
     unsigned char numWalls[kTile], numPlanes[kTile], ndd[kTile], nsc[kTile], seen[kTile], hasGrab[kTile];
     int wid[kTile];                             // world id of each slot of the octet (SimState::worldOfSlot), -1 = empty slot
 };
@@ -801,7 +805,7 @@ HSD WallLists list_wall_bodies(OctRes &R, int nbodies) {
         const int sci = valid ? R.scInfo[t >> 3][t & 7] : 0;
         const bool on = sci != 0 && ((R.scAcc[t & 7] >> (sci & 0xff)) & ((1u << (sci >> 8)) - 1u)) != 0u;
         const unsigned long long m = __ballot(on);
-        if (on) R.wallBodies[n + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)t;
+        if (on) { R.wallBodies[n + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)t; atomicOr(&R.wallSeen[t & 7], 1u << (t >> 3)); }
         n += __popcll(m);
     }
     wave_sync();
@@ -1171,30 +1175,39 @@ HSD void physics_step(SimState &S, OctRes &R) {
         R.numWalls[L] = w >= 0 ? (unsigned char)S.numWalls[w] : 0;
         R.numPlanes[L] = w >= 0 ? (unsigned char)S.numPlanes[w] : 0;
         R.seen[L] = 0; R.ndd[L] = 0; R.nsc[L] = 0;
+        R.wallSeen[L] = w >= 0 ? (unsigned)S.wallHist[w] : 0u;
     }
     if (L < 4 * kTile) (&R.plane0[0][0])[L] = S.planes((L >> 3) * kMaxPlanes, S.wbeg + (L & 7));
     wave_sync();
     HS_TICK(9)
     phase_pre(S, R);
     HS_TICK(0)
-    // ---- compact list of the octet's existing bodies in slot-major order (a third of the box slots are empty)
+    // ---- compact list of the octet's existing bodies (a third of the box slots are empty).  Its order decides which
+    // round a body belongs to and nothing else.  First the bodies that had a wall manifold in the previous step (contacts
+    // persist: an agent pushing against a wall, a box resting at one), agents before boxes within each group: the wall
+    // manifolds of a body of an earlier round ride in the idle lanes of the last round (last_round) instead of costing the
+    // wave a round of their own.
     int nbodies;
     {
         int base = 0;
 #pragma unroll
-        for (int c = 0; c < ROUNDS; ++c) {
-            // (agents first: they are the bodies that run into walls, and the wall manifolds of a body of an earlier
-            // round ride in the idle lanes of the last one — last_round)
-            const int t = c * 64 + L;
-            const int ord = t >> 3, g = t & 7;
-            const int slot = ord < S.A ? kAgentSlot0 + ord : ord - S.A;
-            const bool on = ord < NS && R.meta[slot][g] != 0;
-            const unsigned long long m = __ballot(on);
-            if (on) R.bodies[base + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)(slot << 3 | g);
-            base += __popcll(m);
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int c = 0; c < ROUNDS; ++c) {
+                const int t = c * 64 + L;
+                const int ord = t >> 3, g = t & 7;
+                const int slot = ord < S.A ? kAgentSlot0 + ord : ord - S.A;
+                const bool hist = ord < NS && ((R.wallSeen[g] >> slot) & 1u) != 0u;
+                const bool on = ord < NS && R.meta[slot][g] != 0 && hist == (pass == 0);
+                const unsigned long long m = __ballot(on);
+                if (on) R.bodies[base + __popcll(m & ((1ull << L) - 1ull))] = (unsigned char)(slot << 3 | g);
+                base += __popcll(m);
+            }
         }
         nbodies = base;
     }
+    wave_sync();
+    if (L < kTile) R.wallSeen[L] = 0u;                // from here on: this step's
     wave_sync();
     // A body keeps its (round, lane) for the whole step: which body it is comes from the list, its ground manifold
     // and the agent's force stay in registers.
@@ -1264,7 +1277,7 @@ HSD void physics_step(SimState &S, OctRes &R) {
     mem_sync();                           // the write-back is complete before a regenerated level overwrites it
     HS_TICK(8)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
-    if (L < kTile && R.wid[L] >= 0) reset_world(S, R.wid[L]);
+    if (L < kTile && R.wid[L] >= 0) { S.wallHist[R.wid[L]] = (int)R.wallSeen[L]; reset_world(S, R.wid[L]); }
     // Publish the octet to k_observe, which runs beside this kernel and takes finished octets in the order of this
     // list: the wave's stores have left it (vmcnt), one lane releases at agent scope (the XCDs' L2s are not coherent
     // with each other) and appends the octet.

@@ -40,6 +40,7 @@ struct SimState {
     int *slotOfWorld;      // [N]
     int *worldOfSlot;      // [ceil(N / 8) * 8]  -1 = empty slot (padding of the last octet)
     int *loadAcc;          // [N] candidate pairs seen since the last k_balance
+    int *wallHist;         // [N] bit s: body slot s had a wall / extra-plane manifold in the previous step (ordering hint only)
     // What k_observe needs to know about the world in a slot, in slot order so that no load waits for worldOfSlot:
     // {world id (-1: empty), numWalls | numPlanes << 8 | curEpisodeStep << 16, counts, teams}.  Rewritten by whoever
     // changes one of them (write_slot_hdr: reset / level generation, checkpoint load, k_balance_commit).
