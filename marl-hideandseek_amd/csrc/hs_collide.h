@@ -434,6 +434,76 @@ HSD AxisResult sat_axes(const HullSrc &sa, const HullSrc &sb, const bool hi) {
     return res;
 }
 
+// Stage 1 for the few pairs that involve the ramp's wedge (a couple per octet and substep, yet a round of their own:
+// the wedge's supports walk its vertices): SIXTEEN lanes per pair, `part` = lane % 16.  A hull pair has at most 12 face
+// normals and 16 edge-direction pairs, so every lane tests at most one of each; the sequential loop's "first maximum
+// wins" is the group's maximum with ties to the lower index, found by a butterfly of shuffles.  Same expressions per
+// axis as sat_axes, so the same result; it is valid on every lane of the group.
+struct AxisCand { float s; int i; };
+HSD AxisCand axis_better(AxisCand a, AxisCand b) { return (b.s > a.s || (b.s == a.s && b.i < a.i)) ? b : a; }
+HSD AxisCand axis_reduce16(AxisCand c) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) c = axis_better(c, AxisCand{__shfl_xor(c.s, m), __shfl_xor(c.i, m)});
+    return c;
+}
+HSD bool group16_any(bool x) {
+    const unsigned long long b = __ballot(x);
+    return ((b >> (threadIdx.x & 48)) & 0xffffull) != 0ull;
+}
+HSD AxisResult sat_axes_wide(const HullSrc &sa, const HullSrc &sb, const int part) {
+    AxisResult res = {0, {0.f, 0.f, 0.f}};
+    const HullRef A = hull_from(sa), B = hull_from(sb);
+    WedgeVerts wa = {}, wb = {};
+    if (A.kind == HULL_WEDGE) wedge_verts(A, wa);
+    if (B.kind == HULL_WEDGE) wedge_verts(B, wb);
+    const float kNone = -3.0e38f;
+    // ---- face normals: lanes [0, nfa) take A's faces against B's vertices, the next nfb lanes B's against A's
+    float bestA, bestB; int fa, fb;
+    {
+        const int nfa = hull_nf(A), nfb = hull_nf(B);
+        const bool mineA = part < nfa, mineB = !mineA && part < nfa + nfb;
+        const int f = mineA ? part : part - nfa;
+        float s = kNone;
+        if (mineA) { const V3 fn = hull_fn(A, f); s = support_min(B, wb, fn) - hull_fd_w(A, wa, f, fn); }
+        else if (mineB) { const V3 fn = hull_fn(B, f); s = support_min(A, wa, fn) - hull_fd_w(B, wb, f, fn); }
+        if (group16_any((mineA || mineB) && s > 0.f)) return res;
+        const AxisCand ca = axis_reduce16(AxisCand{mineA ? s : kNone, mineA ? f : 99});
+        const AxisCand cb = axis_reduce16(AxisCand{mineB ? s : kNone, mineB ? f : 99});
+        bestA = ca.s; fa = ca.i; bestB = cb.s; fb = cb.i;
+    }
+    // ---- edge-direction crosses: pair p = i * bned + j on lane p
+    float bestE = 0.f; int ea = -1, eb = -1; V3 axE = {0.f, 0.f, 0.f};
+    {
+        const V3 ab = B.c - A.c;
+        const int aned = hull_ned(A), bned = hull_ned(B);
+        const int tot = aned * bned;
+        const int i = part / bned, j = part - i * bned;
+        float s = kNone; V3 ax = {0.f, 0.f, 0.f}; bool have = false;
+        if (part < tot) {
+            ax = cross(hull_ed(A, i), hull_ed(B, j));
+            const float l2 = len2(ax);
+            if (!(l2 < 1e-6f)) {
+                ax = ax * (1.f / sqrtf(l2));
+                if (dot(ax, ab) < 0.f) ax = -ax;
+                s = support_min(B, wb, ax) - support_max(A, wa, ax);
+                have = true;
+            }
+        }
+        if (group16_any(have && s > 0.f)) return res;
+        const AxisCand ce = axis_reduce16(AxisCand{have ? s : kNone, have ? part : 99});
+        if (ce.i != 99) {
+            const int src = (threadIdx.x & 48) + ce.i;
+            bestE = ce.s; ea = ce.i / bned; eb = ce.i - ea * bned;
+            axE = {__shfl(ax.x, src), __shfl(ax.y, src), __shfl(ax.z, src)};
+        }
+    }
+    const float bestF = fmaxf(bestA, bestB);
+    if (ea >= 0 && bestE > 0.9f * bestF + 0.0025f) { res.code = 1 | (ea << 4) | (eb << 8); res.ax = axE; return res; }
+    const bool refB = bestB > 0.98f * bestA + 0.00125f;
+    res.code = 2 | ((refB ? fb : fa) << 4) | ((refB ? 1 : 0) << 8);
+    return res;
+}
+
 // Stage 2, sat_contact: contact generation for a colliding pair, one lane (it owns a slice of the LDS clip scratch):
 // the closest points of the two supporting edges, or the incident face clipped against the reference face.
 HSD bool sat_contact(const HullSrc &sa, const HullSrc &sb, const AxisResult &res, const ClipBuf &cb, RawManifold &m) {

@@ -456,7 +456,6 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
 HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
     static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
-    const int total = ic.nwedge > 0 ? wedge0 + ic.nwedge : ic.nbox;
     const int lane = threadIdx.x & 63;
     const bool hi = lane >= kClipLanes;
     int npend = 0;
@@ -468,12 +467,18 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
 #else
 #define HS_SAT_T(x)
 #endif
-    for (int base = 0; base < total; base += kClipLanes) {
+    // rounds over the box-only items, 2 lanes per pair and 32 pairs per round, then over the items with a wedge, 16 lanes
+    // per pair and 4 pairs per round (sat_axes_wide); `lead`: the lane of a pair that files its result
+    const int boxRounds = (ic.nbox + kClipLanes - 1) / kClipLanes, wedgeRounds = (ic.nwedge + 3) / 4;
+    for (int round = 0; round < boxRounds + wedgeRounds; ++round) {
         HS_SAT_T(const long long tr0_ = wall_clock64();)
-        const int it = base + (lane & (kClipLanes - 1));
+        const bool wide = round >= boxRounds;
+        const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * kClipLanes;
+        const int it = wide ? base + (lane >> 4) : base + (lane & (kClipLanes - 1));
+        const bool lead = wide ? (lane & 15) == 0 : !hi;
         AxisResult res = {0, {0.f, 0.f, 0.f}};
         int item = 0;
-        if (it < total && !(it >= ic.nbox && it < wedge0)) {
+        if (wide ? it < wedge0 + ic.nwedge : it < ic.nbox) {
             item = R.u.sat.items[it];
             const int g = item >> 6, idx = item & 63;
             const int w = S.wbeg + g;
@@ -487,7 +492,7 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                 const int p = bsel - kMaxWalls;
                 const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
                 RawManifold raw;
-                if (!hi && collide_hull_plane(hull_ref_body(oa, rld3(R.pos, a, g), rld4(R.rot, a, g)), pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
+                if (lead && collide_hull_plane(hull_ref_body(oa, rld3(R.pos, a, g), rld4(R.rot, a, g)), pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
                     ManS m;
                     m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
                     m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
@@ -502,13 +507,15 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                     atomicOr(&R.scAcc[g], 1u << kk);
                     planeMan = true;
                 }
+            } else if (wide) {
+                res = sat_axes_wide(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), lane & 15);
             } else {
                 res = sat_axes(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), hi);
             }
         }
-        HS_SAT_T(if (ic.nwedge > 0 && base >= wedge0) twedge += wall_clock64() - tr0_;)
-        // the colliding pairs of this round join the pending list (their low lanes hold the results)
-        const bool hit = !hi && res.code != 0;
+        HS_SAT_T(if (wide) twedge += wall_clock64() - tr0_;)
+        // the colliding pairs of this round join the pending list (their lead lanes file the results)
+        const bool hit = lead && res.code != 0;
         const unsigned long long m = __ballot(hit);
         const int nhit = __popcll(m);
         if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, false); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
@@ -528,7 +535,7 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
     if (lane == 0) {      // work counters of the convex tests (tools/phase_timing.py; their atomics disturb the phase times)
         unsigned long long *c = (unsigned long long *)S.phaseTicks + (size_t)10 * gridDim.x + 16 * 1024;
         atomicAdd(&c[0], 1ull); atomicAdd(&c[1], (unsigned long long)ic.nbox); atomicAdd(&c[2], (unsigned long long)ic.nwedge);
-        atomicAdd(&c[3], (unsigned long long)((total + kClipLanes - 1) / kClipLanes)); atomicAdd(&c[4], (unsigned long long)nhit_total);
+        atomicAdd(&c[3], (unsigned long long)(boxRounds + wedgeRounds)); atomicAdd(&c[4], (unsigned long long)nhit_total);
         atomicAdd(&c[5], (unsigned long long)nflush);
         atomicAdd(&c[6], (unsigned long long)tflush); atomicAdd(&c[7], (unsigned long long)(wall_clock64() - tsat0)); atomicAdd(&c[8], (unsigned long long)twedge);
     }
