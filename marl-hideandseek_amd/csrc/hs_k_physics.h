@@ -1284,7 +1284,17 @@ HSD void physics_step(SimState &S, OctRes &R) {
     mem_sync();                           // the write-back is complete before a regenerated level overwrites it
     HS_TICK(8)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
-    if (L < kTile && R.wid[L] >= 0) { S.wallHist[R.wid[L]] = (int)R.wallSeen[L]; reset_world(S, R.wid[L]); }
+    // (the generator works in the LDS the octet no longer needs: hs_k_reset.h GenScratch)
+    static_assert(kTile * sizeof(GenScratch) <= sizeof(OctRes), "the generator's working memory fits the octet's LDS");
+    {
+        const int myWorld = L < kTile ? R.wid[L] : -1;
+        const int mySeen = L < kTile ? (int)R.wallSeen[L] : 0;
+        wave_sync();                      // every lane has read what it needs from the resident set
+        if (myWorld >= 0) {
+            S.wallHist[myWorld] = mySeen;
+            reset_world(S, myWorld, reinterpret_cast<GenScratch *>(&R)[L]);
+        }
+    }
     // Publish the octet to k_observe, which runs beside this kernel and takes finished octets in the order of this
     // list: the wave's stores have left it (vmcnt), one lane releases at agent scope (the XCDs' L2s are not coherent
     // with each other) and appends the octet.

@@ -243,12 +243,18 @@ HSD void sample_placement(const GenWorld &g, RNG &rng, int obj, V3 *pos_out, Q *
     }
 }
 
-HSD void gen_training(GenWorld &g, RNG &rng, RNG &episode_rng, uint32_t flags, int num_hiders, int num_seekers) {
+// The generator's working memory for one world.  The physics kernel, whose tail is the reset, places it in the LDS its
+// octet no longer needs (one per lane of the 8 that regenerate; an odd number of words apart, so the 8 never share a bank)
+// — as a local variable it lives in scratch memory, and the generator's chains of dependent array accesses then cost a
+// round trip to memory each (the step on which all 16 000 worlds regenerate took 2.2 ms).
+struct GenScratch { GenWorld g; WallSet ws; int pad[(sizeof(GenWorld) + sizeof(WallSet)) / 4 % 2 == 0 ? 1 : 2]; };
+static_assert(sizeof(GenScratch) % 8 == 4, "odd word count");
+
+HSD void gen_training(GenWorld &g, WallSet &ws, RNG &rng, RNG &episode_rng, uint32_t flags, int num_hiders, int num_seekers) {
     int total_boxes = rng.sampleI32(3, 10);
     int num_elongated = rng.sampleI32(3, total_boxes);
     int num_cubes = total_boxes - num_elongated;
     {   // populateStaticGeometry geo_gen.cpp:467-505
-        WallSet ws;
         make_walls(ws, rng);
         const float mn = -18.f, range = 18.f - (-18.f);
         g.numWalls = ws.n;
@@ -313,7 +319,7 @@ HSD void gen_debug(GenWorld &g, int level) {                    // level_gen.cpp
 // step come from the checkpoint, the world's episode counter is not advanced and the saved body /
 // joint state is written over the generated spawn state.
 template <bool LOAD>
-HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoint *ck) {
+HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoint *ck, GenScratch &scratch) {
     const int N = S.N;
     const int ps = S.slotOfWorld[w];        // the world's slot in the tiled columns (hs_state.h)
     uint32_t ep, world_id;
@@ -339,7 +345,7 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
     RandKey lvl = erng.randKey();
     if ((S.flags & FLAG_USE_FIXED_WORLD) == FLAG_USE_FIXED_WORLD) lvl = {0u, 0u};
 
-    GenWorld g;
+    GenWorld &g = scratch.g;
     g.numWalls = 0; g.numPlanes = 0;
     g.numHiders = g.numSeekers = g.numActiveAgents = g.numActiveBoxes = g.numActiveRamps = 0;
     g.seekersFirst = cnt_seekers_first(S.counts[w]);   // TeamState persists across debug levels
@@ -350,7 +356,7 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
         g.resp[i] = RESP_STATIC; g.owner[i] = OWNER_NONE; g.lin[i] = {0.f, 0.f, 0.f};
     }
     RNG lrng; lrng.k = lvl; lrng.count = 0;
-    if (LOAD || level == 1) gen_training(g, lrng, erng, S.flags, nh, ns);
+    if (LOAD || level == 1) gen_training(g, scratch.ws, lrng, erng, S.flags, nh, ns);
     else gen_debug(g, level);
 
     // ---- write back
@@ -441,7 +447,7 @@ HSD void write_slot_hdr(const SimState &S, int w, int ps) {
 }
 
 // resetSystem (src/sim.cpp:172-200) for one world
-HSD void reset_world(const SimState &S, int w) {
+HSD void reset_world(const SimState &S, int w, GenScratch &scratch) {
     int level = S.xReset[w];
     const int step = S.curEpisodeStep[w];
     if ((S.flags & FLAG_IGNORE_EPISODE_LENGTH) != FLAG_IGNORE_EPISODE_LENGTH && step == kEpisodeLen - 1) level = 1;
@@ -451,7 +457,7 @@ HSD void reset_world(const SimState &S, int w) {
         write_slot_hdr(S, w, S.slotOfWorld[w]);
         return;
     }
-    regenerate_world<false>(S, w, level, nullptr);
+    regenerate_world<false>(S, w, level, nullptr, scratch);
     write_slot_hdr(S, w, S.slotOfWorld[w]);
 }
 
@@ -460,7 +466,8 @@ HSD void reset_world(const SimState &S, int w) {
 __global__ void __launch_bounds__(64) k_reset(SimState S) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= S.N) return;
-    reset_world(S, w);
+    GenScratch scratch;
+    reset_world(S, w, scratch);
 }
 
 // lidarSystem angles (sim.cpp:727-738): the same 30 values for every agent of every world; once per simulator.
@@ -477,7 +484,8 @@ __global__ void __launch_bounds__(64) k_load_ckpt(SimState S) {
     if (w >= S.N) return;
     if (S.xCkptCtrl[w] == 0) return;
     S.xCkptCtrl[w] = 1;
-    regenerate_world<true>(S, w, 1, (const hs_checkpoint *)S.xCkpt + w);
+    GenScratch scratch;
+    regenerate_world<true>(S, w, 1, (const hs_checkpoint *)S.xCkpt + w, scratch);
     write_slot_hdr(S, w, S.slotOfWorld[w]);
 }
 
