@@ -1136,7 +1136,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
 // ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
 // 6 agents (17 slots x 8 worlds = 136 bodies at most).
 template <int ROUNDS>
-HSD void physics_step(SimState &S, OctRes &R) {
+HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     const int L = threadIdx.x, o = blockIdx.x;
     S.wbeg = o * kTile;                               // first slot of the octet in the tiled columns
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
@@ -1285,14 +1285,13 @@ HSD void physics_step(SimState &S, OctRes &R) {
     HS_TICK(8)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
     // (the generator works in the LDS the octet no longer needs: hs_k_reset.h GenScratch)
-    static_assert(kTile * sizeof(GenScratch) <= sizeof(OctRes), "the generator's working memory fits the octet's LDS");
     {
         const int myWorld = L < kTile ? R.wid[L] : -1;
         const int mySeen = L < kTile ? (int)R.wallSeen[L] : 0;
         wave_sync();                      // every lane has read what it needs from the resident set
         if (myWorld >= 0) {
             S.wallHist[myWorld] = mySeen;
-            reset_world(S, myWorld, reinterpret_cast<GenScratch *>(&R)[L]);
+            reset_world(S, myWorld, gen[L]);
         }
     }
     // Publish the octet to k_observe, which runs beside this kernel and takes finished octets in the order of this
@@ -1322,8 +1321,10 @@ HSD void physics_step(SimState &S, OctRes &R) {
 
 template <int ROUNDS>
 __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
-    __shared__ OctRes R;
-    physics_step<ROUNDS>(S, R);
+    // (the generator's working memory — the reset at the tail of the step — shares the octet's LDS: hs_k_reset.h GenScratch)
+    __shared__ union PhysLds { OctRes R; GenScratch gen[kTile]; } lds;
+    static_assert(sizeof(PhysLds) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
+    physics_step<ROUNDS>(S, lds.R, lds.gen);
 }
 
 // Holds the stream of k_observe back until every wave of k_physics has started, i.e. holds its slot on a CU: the

@@ -199,6 +199,7 @@ struct GenWorld {
     int numWalls; float wcx[kMaxWalls], wcy[kMaxWalls], whx[kMaxWalls], why[kMaxWalls];
     int obj[kNumDSlots]; V3 pos[kNumDSlots]; Q rot[kNumDSlots]; int resp[kNumDSlots]; int owner[kNumDSlots];
     V3 lin[kNumDSlots];
+    AABB box[kAgentSlot0];           // world AABB of every placed box / ramp (what placement_free tests against), computed once
     int numPlanes; V3 pn[kMaxPlanes]; float pd[kMaxPlanes];
     int numHiders, numSeekers, numActiveAgents, numActiveBoxes, numActiveRamps, seekersFirst;
     int hiders[3], seekers[3]; int agentType[kMaxAgents];
@@ -207,6 +208,7 @@ struct GenWorld {
 HSD void gen_put(GenWorld &g, int slot, V3 p, Q r, int obj, int resp = RESP_DYNAMIC, int owner = OWNER_NONE) {
     g.obj[slot] = obj; g.pos[slot] = p; g.rot[slot] = r; g.resp[slot] = resp; g.owner[slot] = owner;
     g.lin[slot] = {0.f, 0.f, 0.f};
+    if (slot < kAgentSlot0) g.box[slot] = aabb_apply_tr(object_aabb(obj), p, r);
 }
 HSD void gen_agent(GenWorld &g, V3 p, Q r, int type) {          // makeAgent level_gen.cpp:12-66
     int idx = g.numActiveAgents++;
@@ -223,8 +225,7 @@ HSD bool placement_free(const GenWorld &g, const AABB &a) {     // level_gen.cpp
     }
     for (int s = 0; s < kAgentSlot0; ++s) {
         if (g.obj[s] == OBJ_NONE) continue;
-        AABB o = aabb_apply_tr(object_aabb(g.obj[s]), g.pos[s], g.rot[s]);
-        if (aabb_overlaps(a, o)) return false;
+        if (aabb_overlaps(a, g.box[s])) return false;        // (= aabb_apply_tr(object_aabb(obj), pos, rot), kept since gen_put)
     }
     return true;
 }
