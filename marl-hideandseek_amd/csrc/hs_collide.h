@@ -70,6 +70,12 @@ HSD V3 wedge_local_fn(int f) {    // {0,0,-1},{0,1,0},{0,-2,3}/sqrt13,{1,0,0},{-
     return {-1.f, 0.f, 0.f};
 }
 
+// One of four values by index, through bit masks: written as a chain of conditionals on a per-lane index the
+// compiler parks the candidates in scratch memory and indexes them there — stores that show up as HBM write traffic.
+HSD float sel4_bits(int i, float a, float b, float c, float d) {
+    const unsigned m0 = i == 0 ? ~0u : 0u, m1 = i == 1 ? ~0u : 0u, m2 = i == 2 ? ~0u : 0u, m3 = i >= 3 ? ~0u : 0u;
+    return __uint_as_float((__float_as_uint(a) & m0) | (__float_as_uint(b) & m1) | (__float_as_uint(c) & m2) | (__float_as_uint(d) & m3));
+}
 HSD int hull_nv(const HullRef &h) { return h.kind == HULL_WEDGE ? 6 : 8; }
 HSD int hull_nf(const HullRef &h) { return h.kind == HULL_WEDGE ? 5 : 6; }
 HSD int hull_ned(const HullRef &h) { return h.kind == HULL_WEDGE ? 4 : 3; }
@@ -86,7 +92,8 @@ HSD V3 hull_fn(const HullRef &h, int f) {
         V3 l = wedge_local_fn(f);
         return (h.ax * l.x + h.ay * l.y) + h.az * l.z;
     }
-    V3 a = (f >> 1) == 0 ? h.ax : ((f >> 1) == 1 ? h.ay : h.az);
+    const int k = f >> 1;
+    const V3 a = {sel4_bits(k, h.ax.x, h.ay.x, h.az.x, h.az.x), sel4_bits(k, h.ax.y, h.ay.y, h.az.y, h.az.y), sel4_bits(k, h.ax.z, h.ay.z, h.az.z, h.az.z)};
     return (f & 1) ? a : -a;
 }
 HSD int hull_fcnt(const HullRef &h, int f) { return (h.kind == HULL_WEDGE && f >= 3) ? 3 : 4; }
@@ -98,10 +105,8 @@ HSD float hull_fd(const HullRef &h, int f, V3 fn) {
     return dot(fn, h.c) + ei;
 }
 HSD V3 hull_ed(const HullRef &h, int i) {
-    if (i == 0) return h.ax;
-    if (i == 1) return h.ay;
-    if (i == 2) return h.az;
-    return (h.ax * 0.f + h.ay * 0.832050294f) + h.az * 0.554700196f;
+    const V3 s = (h.ax * 0.f + h.ay * 0.832050294f) + h.az * 0.554700196f;
+    return {sel4_bits(i, h.ax.x, h.ay.x, h.az.x, s.x), sel4_bits(i, h.ax.y, h.ay.y, h.az.y, s.y), sel4_bits(i, h.ax.z, h.ay.z, h.az.z, s.z)};
 }
 HSD void hull_edge(const HullRef &h, int e, int *v0, int *v1, int *dir) {
     if (h.kind == HULL_WEDGE) wedge_edge(e, v0, v1, dir); else box_edge(e, v0, v1, dir);
@@ -197,7 +202,7 @@ HSD float hull_fd_w(const HullRef &h, const WedgeVerts &wv, int f, V3 fn) {
         const V3 v = i == 4 ? wv.v[4] : (i == 2 ? wv.v[2] : (i == 1 ? wv.v[1] : wv.v[5]));
         return dot(fn, v);
     }
-    const float ei = (f >> 1) == 0 ? h.e.x : ((f >> 1) == 1 ? h.e.y : h.e.z);
+    const float ei = sel4_bits(f >> 1, h.e.x, h.e.y, h.e.z, h.e.z);
     return dot(fn, h.c) + ei;
 }
 

@@ -915,34 +915,34 @@ HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int sl
     while (todo != 0u) {
         const int k = bsc + __ffs((int)todo) - 1;
         todo &= todo - 1u;
-        V3 n, rA[4]; float mu, off[4], lam[4]; int np, loc = kLocGlobal;
+        // (no arrays indexed by the contact number here: in scratch memory they cost a store and a load per contact)
+        V3 n; float mu; int np, loc = kLocGlobal;
+        ManS m;
         if (walls) {
             loc = pair_loc(R.scPair[k][g]);
-            ManS m;
             if (loc != kLocGlobal) man_lds_load(R.u.sat.clip, loc, m); else m = wsSC[k];
             n = ld3(m.n); mu = POS ? m.muS : m.muD; np = m.np;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { rA[j] = ld3(m.rA[j]); off[j] = m.offB[j]; lam[j] = m.lam[j]; }
         } else {
             n = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
             mu = POS ? 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE)) : 0.5f * (obj_mu_d(obj) + obj_mu_d(OBJ_PLANE));
             np = b.np;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { rA[j] = hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7); off[j] = b.off[j]; lam[j] = b.lam[j]; }
         }
         body_refresh_inertia(me);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < np) {
-                if (POS) {
-                    const float nl = lam[j] + solve_point_position<false>(me, none, n, rA[j], V3{0.f, 0.f, 0.f}, off[j], mu);
-                    if (!walls) b.lam[j] = nl;
-                    else if (loc != kLocGlobal) man_lds_set_lam<ManS>(R.u.sat.clip, loc, j, nl);
-                    else wsSC[k].lam[j] = nl;
-                } else {
-                    solve_point_velocity<false>(me, none, n, rA[j], V3{0.f, 0.f, 0.f}, lam[j], mu);
-                }
-            }
+#define HS_LAST_POINT(j)                                                                                                   \
+        if ((j) < np) {                                                                                                    \
+            const V3 rAj = walls ? ld3(m.rA[j]) : hull_local_vertex(obj, (b.vidx >> (3 * (j))) & 7);                       \
+            const float lamj = walls ? m.lam[j] : b.lam[j];                                                                \
+            if (POS) {                                                                                                     \
+                const float nl = lamj + solve_point_position<false>(me, none, n, rAj, V3{0.f, 0.f, 0.f}, walls ? m.offB[j] : b.off[j], mu); \
+                if (!walls) b.lam[j] = nl;                                                                                 \
+                else if (loc != kLocGlobal) man_lds_set_lam<ManS>(R.u.sat.clip, loc, (j), nl);                             \
+                else wsSC[k].lam[j] = nl;                                                                                  \
+            } else {                                                                                                       \
+                solve_point_velocity<false>(me, none, n, rAj, V3{0.f, 0.f, 0.f}, lamj, mu);                                \
+            }                                                                                                              \
+        }
+        HS_LAST_POINT(0) HS_LAST_POINT(1) HS_LAST_POINT(2) HS_LAST_POINT(3)
+#undef HS_LAST_POINT
     }
     if (POS) rbody_store_pose(R, g, slot, me); else rbody_store_vel(R, g, slot, me);
 }
