@@ -101,7 +101,7 @@ HSD int hull_fidx(const HullRef &h, int f, int k) { return h.kind == HULL_WEDGE 
 // plane offset of face f (normal fn): closed form for boxes, first loop vertex for the wedge
 HSD float hull_fd(const HullRef &h, int f, V3 fn) {
     if (h.kind == HULL_WEDGE) return dot(fn, hull_v(h, wedge_face_idx(f, 0)));
-    const float ei = (f >> 1) == 0 ? h.e.x : ((f >> 1) == 1 ? h.e.y : h.e.z);
+    const float ei = sel4_bits(f >> 1, h.e.x, h.e.y, h.e.z, h.e.z);
     return dot(fn, h.c) + ei;
 }
 HSD V3 hull_ed(const HullRef &h, int i) {
@@ -198,8 +198,10 @@ HSD float support_max(const HullRef &h, const WedgeVerts &wv, V3 n) {
 // plane offset of face f: closed form for boxes, first loop vertex for the wedge
 HSD float hull_fd_w(const HullRef &h, const WedgeVerts &wv, int f, V3 fn) {
     if (h.kind == HULL_WEDGE) {
-        const int i = wedge_face_idx(f, 0);       // 4, 4, 2, 1, 5
-        const V3 v = i == 4 ? wv.v[4] : (i == 2 ? wv.v[2] : (i == 1 ? wv.v[1] : wv.v[5]));
+        // first loop vertex of face f: 4, 4, 2, 1, 5
+        const int k = f < 2 ? 0 : f - 1;
+        const V3 v = {sel4_bits(k, wv.v[4].x, wv.v[2].x, wv.v[1].x, wv.v[5].x), sel4_bits(k, wv.v[4].y, wv.v[2].y, wv.v[1].y, wv.v[5].y),
+                      sel4_bits(k, wv.v[4].z, wv.v[2].z, wv.v[1].z, wv.v[5].z)};
         return dot(fn, v);
     }
     const float ei = sel4_bits(f >> 1, h.e.x, h.e.y, h.e.z, h.e.z);
