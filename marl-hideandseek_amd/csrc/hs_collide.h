@@ -448,9 +448,17 @@ HSD AxisResult sat_axes(const HullSrc &sa, const HullSrc &sb, const bool hi) {
 // axis as sat_axes, so the same result; it is valid on every lane of the group.
 struct AxisCand { float s; int i; };
 HSD AxisCand axis_better(AxisCand a, AxisCand b) { return (b.s > a.s || (b.s == a.s && b.i < a.i)) ? b : a; }
+// all-reduce over the 16 lanes of a DPP row: pairs and quads by quad_perm, then the other quad of the half row
+// (row_half_mirror) and the other half row (row_mirror) — after each step all lanes of the combined group agree
+template <int CTRL> HSD AxisCand axis_dpp(AxisCand c) {
+    return {__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c.s), CTRL, 0xF, 0xF, false)),
+            __builtin_amdgcn_update_dpp(0, c.i, CTRL, 0xF, 0xF, false)};
+}
 HSD AxisCand axis_reduce16(AxisCand c) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) c = axis_better(c, AxisCand{__shfl_xor(c.s, m), __shfl_xor(c.i, m)});
+    c = axis_better(c, axis_dpp<0xB1>(c));      // quad_perm [1,0,3,2]
+    c = axis_better(c, axis_dpp<0x4E>(c));      // quad_perm [2,3,0,1]
+    c = axis_better(c, axis_dpp<0x141>(c));     // row_half_mirror
+    c = axis_better(c, axis_dpp<0x140>(c));     // row_mirror
     return c;
 }
 HSD bool group16_any(bool x) {

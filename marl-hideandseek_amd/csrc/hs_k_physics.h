@@ -136,6 +136,32 @@ HSD void derive_velocity(BodyS &b) {
 HSD void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 HSD void mem_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
+// Prefix sums and totals across lanes by DPP (one vector instruction per step) instead of shuffles through the LDS
+// crossbar (a round trip each, and the broadphase chains a dozen of them).
+template <int D> HSD int dpp_row_shr(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x110 + D, 0xF, 0xF, true); }   // lane i <- lane i - D of its row of 16, 0 beyond
+// inclusive prefix sum over the 8 lanes of a world (l = lane % 8): the steps' reach never leaves the group where it counts
+HSD int scan8_incl(int x, int l) {
+    int y;
+    y = dpp_row_shr<1>(x); if (l >= 1) x += y;
+    y = dpp_row_shr<2>(x); if (l >= 2) x += y;
+    y = dpp_row_shr<4>(x); if (l >= 4) x += y;
+    return x;
+}
+// sum over the 8 lanes of a world, in every lane: pairs, quads (quad_perm), then the two quads of the half row (mirror)
+HSD int sum8_all(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);     // row_half_mirror
+    return x;
+}
+// inclusive prefix sum over the wave's 64 lanes
+HSD int scan64_incl(int x) {
+    x += dpp_row_shr<1>(x); x += dpp_row_shr<2>(x); x += dpp_row_shr<4>(x); x += dpp_row_shr<8>(x);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // Geometry view of one world of the octet for trace_ray (hs_rays.h): bodies from the resident columns, walls and
 // the (at most 3) planes from global memory (the rays of the physics kernel — lock / grab, seeker -> hider line
 // of sight — are few; the lidar / visibility rays are k_observe's).
@@ -292,14 +318,9 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
     for (int jb = 0; jb < JB; ++jb) {
         if (dynamic[jb]) for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
         const int cdd = __popc(dd_mask[jb]), csc = __popcll(s_mask[jb]);
-        int in_dd = cdd, in_sc = csc;
-#pragma unroll
-        for (int d = 1; d < G; d <<= 1) {
-            const int y0 = __shfl_up(in_dd, d, G), y1 = __shfl_up(in_sc, d, G);
-            if (l >= d) { in_dd += y0; in_sc += y1; }
-        }
+        const int in_dd = scan8_incl(cdd, l), in_sc = scan8_incl(csc, l);
         bdd[jb] = tot_dd + in_dd - cdd; bsc[jb] = tot_sc + in_sc - csc;
-        tot_dd += __shfl(in_dd, G - 1, G); tot_sc += __shfl(in_sc, G - 1, G);
+        tot_dd += sum8_all(cdd); tot_sc += sum8_all(csc);
         add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
@@ -319,14 +340,9 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         else { unsigned mm = dd_mask[jb]; for (int i = 0; mm && i < add[jb]; ++i) { const int j = __ffs(mm) - 1; mm &= mm - 1; n_wedge += (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps) ? 1 : 0; } }
     }
     const int n_box = tot_items - n_wedge;
-    int inc_box = n_box, inc_wedge = n_wedge;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y0 = __shfl_up(inc_box, d), y1 = __shfl_up(inc_wedge, d);
-        if (L >= d) { inc_box += y0; inc_wedge += y1; }
-    }
+    const int inc_box = scan64_incl(n_box), inc_wedge = scan64_incl(n_wedge);
     ItemCounts ic;
-    ic.nbox = __shfl(inc_box, 63); ic.nwedge = __shfl(inc_wedge, 63);
+    ic.nbox = __builtin_amdgcn_readlane(inc_box, 63); ic.nwedge = __builtin_amdgcn_readlane(inc_wedge, 63);
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     int ibox = inc_box - n_box, iwedge = wedge0 + inc_wedge - n_wedge;
     wave_sync();                          // every lane is done with the walls: the work list may overwrite them
