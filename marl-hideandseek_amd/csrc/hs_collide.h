@@ -376,13 +376,16 @@ HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, con
 // The convex test in two stages, so that the (long, single-lane) contact generation runs only for the pairs that do
 // collide, compacted over the wave's items, and neither stage has to keep the other's registers.
 //
-// Stage 1, sat_axes: the separating-axis search.  Two lanes of a wave — lane L and lane L + 32, `hi` on the second —
+// Stage 1, sat_axes: the separating-axis search.  Two neighbouring lanes of a wave — 2k and 2k + 1, `hi` on the second —
 // run it together on the SAME pair: the low lane tests A's face normals and the first half of the edge-direction
 // pairs, its partner B's face normals and the second half; they exchange results with cross-lane shuffles and
 // combine them exactly as the sequential loop would (strictly-greater updates, earlier axis wins ties).  The result
 // is valid on the low lane:  code 0 = separated;  1 | ea << 4 | eb << 8 = edge contact along `ax`;
 // 2 | face << 4 | refB << 8 = face contact with reference face `face` of B (refB) or A.
 struct AxisResult { int code; V3 ax; };
+// the partner lane of a pair is its neighbour (lanes 2k, 2k + 1): one DPP move instead of a trip through the LDS crossbar
+HSD int pair_swap(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); }
+HSD float pair_swap(float x) { return __int_as_float(pair_swap(__float_as_int(x))); }
 HSD AxisResult sat_axes(const HullSrc &sa, const HullSrc &sb, const bool hi) {
     AxisResult res = {0, {0.f, 0.f, 0.f}};
     // ---- face normals: this lane takes the faces of X against the vertices of Y (X = A on the low lane, B on its partner)
@@ -400,8 +403,8 @@ HSD AxisResult sat_axes(const HullSrc &sa, const HullSrc &sb, const bool hi) {
             if (s > 0.f) { sep = 1; break; }
             if (fx < 0 || s > best) { best = s; fx = f; }
         }
-        const float best_o = __shfl_xor(best, 32); const int fx_o = __shfl_xor(fx, 32);
-        if (sep | __shfl_xor(sep, 32)) return res;
+        const float best_o = pair_swap(best); const int fx_o = pair_swap(fx);
+        if (sep | pair_swap(sep)) return res;
         bestA = hi ? best_o : best; fa = hi ? fx_o : fx;
         bestB = hi ? best : best_o; fb = hi ? fx : fx_o;
     }
@@ -427,9 +430,9 @@ HSD AxisResult sat_axes(const HullSrc &sa, const HullSrc &sb, const bool hi) {
             if (s > 0.f) { sep = 1; break; }
             if (ea < 0 || s > bestE) { bestE = s; ea = i; eb = j; axE = ax; }
         }
-        if (sep | __shfl_xor(sep, 32)) return res;
-        const float bE_o = __shfl_xor(bestE, 32); const int ea_o = __shfl_xor(ea, 32), eb_o = __shfl_xor(eb, 32);
-        const V3 ax_o = {__shfl_xor(axE.x, 32), __shfl_xor(axE.y, 32), __shfl_xor(axE.z, 32)};
+        if (sep | pair_swap(sep)) return res;
+        const float bE_o = pair_swap(bestE); const int ea_o = pair_swap(ea), eb_o = pair_swap(eb);
+        const V3 ax_o = {pair_swap(axE.x), pair_swap(axE.y), pair_swap(axE.z)};
         if (hi) return res;                   // the low lane holds the result
         // sequential semantics: the second half replaces the first half's best only if strictly greater
         if (ea_o >= 0 && (ea < 0 || bE_o > bestE)) { bestE = bE_o; ea = ea_o; eb = eb_o; axE = ax_o; }

@@ -16,7 +16,7 @@
 //              benchmark's ~12 bodies per world): integrate, ground + wall contacts, velocity pass.  A body keeps
 //              its (round, lane) for the whole step, so its ground manifold lives in registers.
 //   worlds     8 lanes per world (world = L / 8): broadphase, body-body solve, rewards.
-//   pairs      2 lanes per candidate pair (L and L + 32): exact convex test.
+//   pairs      2 neighbouring lanes per candidate pair (16 per pair with a wedge): exact convex test.
 // Substep s:  [integrate s=0] -> detect -> sat -> dd<pos> -> body_pos -> dd<vel> -> body_vel (+ integrate s+1)
 // The Gauss-Seidel order and every rounding are the oracle's (joints, body-body in pair order, then per body:
 // ground, walls by static id).
@@ -382,7 +382,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
 
 // ------------------------------------------------------------------------------------------
 // Exact convex tests, in two stages (hs_collide.h).  Stage 1 — the separating-axis search — runs over all the
-// octet's candidate pairs, two lanes per pair (L and L + 32), 32 pairs per round; the pairs that collide are appended
+// octet's candidate pairs, two lanes per pair (2k and 2k + 1), 32 pairs per round; the pairs that collide are appended
 // to a pending list.  Stage 2 — contact generation, the long part: polygon clipping on one lane — runs on the pending
 // pairs only, compacted, 32 per round: about a third of the candidates collide, so one round serves the whole octet.
 HSD HullSrc sat_hull_a(const OctRes &R, int g, int a) { return hull_src_body(meta_obj(R.meta[a][g]), rld3(R.pos, a, g), rld4(R.rot, a, g)); }
@@ -470,10 +470,9 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
 // Returns whether any manifold of the substep lies in the global workspace (wave-uniform): only then do the solver
 // phases have to wait for global memory at all.
 HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
-    static_assert(kClipLanes == 32, "lane L pairs with lane L + 32");
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     const int lane = threadIdx.x & 63;
-    const bool hi = lane >= kClipLanes;
+    const bool hi = (lane & 1) != 0;                  // the second lane of a pair (box rounds: lanes 2k, 2k + 1)
     int npend = 0;
     bool usedGlobal = false, planeMan = false;
     int nhit_total = 0, nflush = 0;      // (counters of the HS_PHASE_TIMING build)
@@ -490,7 +489,7 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         HS_SAT_T(const long long tr0_ = wall_clock64();)
         const bool wide = round >= boxRounds;
         const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * kClipLanes;
-        const int it = wide ? base + (lane >> 4) : base + (lane & (kClipLanes - 1));
+        const int it = wide ? base + (lane >> 4) : base + (lane >> 1);
         const bool lead = wide ? (lane & 15) == 0 : !hi;
         AxisResult res = {0, {0.f, 0.f, 0.f}};
         int item = 0;
