@@ -6,7 +6,7 @@ mkdir -p gpurun_out/prof_$tag
 python3 marl-hideandseek_amd/build.py --timing > /dev/null || exit 1
 O=gpurun_out/prof_$tag
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
-HS_OVERLAP=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/bench_overlap.json 2>> $O/bench.err || exit 1
+HS_OVERLAP=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/bench_overlap.json 2>> $O/bench.err || echo "overlap run failed (opt-in schedule; see bench.err)"
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --worlds-per-gpu 65536 --flags 65536 --steps 480 > $O/bench_physics_only_65536.json 2>> $O/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --worlds-per-gpu 16384 --steps 960 > $O/bench_shard_16384.json 2>> $O/bench.err || exit 1
 bash tools/kstats.sh > $O/kstats.txt 2>&1 || exit 1
