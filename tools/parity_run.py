@@ -36,12 +36,14 @@ def main():
     ap.add_argument("--level", type=int, default=0, help="debug level for all worlds (0 = training)")
     ap.add_argument("--act", default="bench", choices=["bench", "full", "none"])
     ap.add_argument("--stop", action="store_true", help="stop at first mismatch")
+    ap.add_argument("--threads", type=int, default=8, help="oracle threads")
+    ap.add_argument("--every", type=int, default=1, help="compare every n-th step (and the last one)")
     a = ap.parse_args()
 
     import torch
     N = a.worlds
     ref = hs_ref.RefSim(N, sim_flags=a.flags, rand_seed=a.seed, min_hiders=a.hiders, max_hiders=a.hiders,
-                        min_seekers=a.seekers, max_seekers=a.seekers, threads=8)
+                        min_seekers=a.seekers, max_seekers=a.seekers, threads=a.threads)
     sim = gpu_hideseek.HideAndSeekSimulator(
         exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=N, sim_flags=a.flags,
         rand_seed=a.seed, min_hiders=a.hiders, max_hiders=a.hiders, min_seekers=a.seekers,
@@ -102,9 +104,10 @@ def main():
             gt["action"].copy_(torch.from_numpy(act).to(gt["action"].device))
         ref.step()
         sim.step()
-        ok = compare(f"step {s}")
-        if not ok and a.stop:
-            break
+        if s % a.every == 0 or s == a.steps - 1:
+            ok = compare(f"step {s}")
+            if not ok and a.stop:
+                break
     print(f"done: {a.steps} steps, {N} worlds, mismatching checkpoints: {nbad}")
     return 1 if nbad else 0
 
