@@ -816,12 +816,12 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
 // the octet (wallBodies) — between the ground pass and the velocity derivation.
 struct WallLists { int nwb, nEarly; };     // listed bodies; how many of them belong to a round before the last one
 template <int ROUNDS>
-HSD WallLists list_wall_bodies(OctRes &R, int nbodies) {
+HSD WallLists list_wall_bodies(OctRes &R, int nbodies, int lastRound) {
     const int L = threadIdx.x;
     int n = 0, nEarly = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        if (r == ROUNDS - 1) nEarly = n;
+        if (r == lastRound) nEarly = n;
         const bool valid = r * 64 + L < nbodies;
         const int t = valid ? R.bodies[r * 64 + L] : 0;
         const int sci = valid ? R.scInfo[t >> 3][t & 7] : 0;
@@ -1148,6 +1148,26 @@ HSD void phase_post(const SimState &S, OctRes &R) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The static-contact passes of a substep: ground_pos / ground_vel for the rounds before LASTR, then last_round for round
+// LASTR (the last round that holds bodies) with the wall manifolds of earlier rounds' bodies in its idle lanes.
+template <int ROUNDS, int LASTR, bool POS>
+HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int nLast, int nMerged) {
+    const int L = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < LASTR; ++r) {
+        const bool valid = r * 64 + L < nbodies; const int t_ = valid ? R.bodies[r * 64 + L] : 0;
+        const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
+        if (valid) { if (POS) ground_pos(R, br[r], slot, g, meta); else ground_vel(R, br[r], slot, g, meta); }
+    }
+    wave_sync();                          // (the poses / velocities of the earlier rounds, for the merged lanes)
+    {
+        const bool valid = LASTR * 64 + L < nbodies; const int t_ = valid ? R.bodies[LASTR * 64 + L] : 0;
+        const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
+        last_round<POS>(S, R, br[LASTR], valid, slot, g, meta, nLast, nMerged);
+    }
+    wave_sync();
+}
+
 // ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
 // 6 agents (17 slots x 8 worlds = 136 bodies at most).
 template <int ROUNDS>
@@ -1261,14 +1281,15 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         HS_TICK(3)
         phase_dd<true>(S, R);
         HS_TICK(4)
-        const WallLists wl = list_wall_bodies<ROUNDS>(R, nbodies);
-        const int nLast = max(nbodies - 64 * (ROUNDS - 1), 0);          // bodies of the last round
+        // (with 6 agents a third round exists for up to 136 bodies, but an octet rarely holds more than 128: then round 1 is
+        // the last one that holds bodies, and the passes are two, not three)
+        const bool shortLast = ROUNDS == 3 && nbodies <= 128;
+        const int lastRound = shortLast ? 1 : ROUNDS - 1;
+        const WallLists wl = list_wall_bodies<ROUNDS>(R, nbodies, lastRound);
+        const int nLast = max(nbodies - 64 * lastRound, 0);            // bodies of the last round
         const int nMerged = min(wl.nEarly, 64 - nLast);                 // listed bodies its idle lanes take
-#pragma unroll
-        for (int r = 0; r < ROUNDS - 1; ++r) { HS_BODY(r) if (valid) ground_pos(R, br[r], slot, g, meta); }
-        wave_sync();                      // (the poses of the earlier rounds, for the merged lanes)
-        { HS_BODY(ROUNDS - 1) last_round<true>(S, R, br[ROUNDS - 1], valid, slot, g, meta, nLast, nMerged); }
-        wave_sync();
+        if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), true>(S, R, br, nbodies, nLast, nMerged);
+        else static_passes<ROUNDS, ROUNDS - 1, true>(S, R, br, nbodies, nLast, nMerged);
         if (wl.nwb > nMerged) { wall_round<true>(S, R, nMerged, wl.nwb); wave_sync(); }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
@@ -1276,11 +1297,8 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         HS_TICK(5)
         phase_dd<false>(S, R);
         HS_TICK(6)
-#pragma unroll
-        for (int r = 0; r < ROUNDS - 1; ++r) { HS_BODY(r) if (valid) ground_vel(R, br[r], slot, g, meta); }
-        wave_sync();
-        { HS_BODY(ROUNDS - 1) last_round<false>(S, R, br[ROUNDS - 1], valid, slot, g, meta, nLast, nMerged); }
-        wave_sync();
+        if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), false>(S, R, br, nbodies, nLast, nMerged);
+        else static_passes<ROUNDS, ROUNDS - 1, false>(S, R, br, nbodies, nLast, nMerged);
         if (wl.nwb > nMerged) { wall_round<false>(S, R, nMerged, wl.nwb); wave_sync(); }
         if (sub + 1 < kNumSubsteps) {
 #pragma unroll
