@@ -12,14 +12,16 @@
 // ~27 clocks.)
 //
 // Lane mappings inside the wave (L = lane):
-//   bodies     compact list of the octet's existing bodies in slot-major order, 64 per round (2 rounds for the
-//              benchmark's ~12 bodies per world): integrate, ground + wall contacts, velocity pass.  A body keeps
-//              its (round, lane) for the whole step, so its ground manifold lives in registers.
+//   bodies     compact list of the octet's existing bodies, 64 per round (2 rounds for the benchmark's ~12 bodies per
+//              world; bodies with a wall contact in the previous step first, agents before boxes): integrate, ground
+//              contacts, velocity pass; the last round's idle lanes solve the wall manifolds of earlier rounds'
+//              bodies.  A body keeps its (round, lane) for the whole step: its ground manifold lives in registers.
 //   worlds     8 lanes per world (world = L / 8): broadphase, body-body solve, rewards.
 //   pairs      2 neighbouring lanes per candidate pair (16 per pair with a wedge): exact convex test.
 // Substep s:  [integrate s=0] -> detect -> sat -> dd<pos> -> body_pos -> dd<vel> -> body_vel (+ integrate s+1)
 // The Gauss-Seidel order and every rounding are the oracle's (joints, body-body in pair order, then per body:
-// ground, walls by static id).
+// ground, walls by static id).  The contact manifolds of a substep live in LDS (manifold slots in the clip buffers),
+// the level generator at the tail of the step works in the octet's LDS as well: the kernel uses no scratch memory.
 #pragma once
 #include "hs_state.h"
 #include "hs_rays.h"
