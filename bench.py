@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--profile-every", type=int, default=0,
-                    help="steps between two steps that carry HIP events (0: 7, or 1 for runs of at most 64 steps)")
+                    help="steps between two steps that carry HIP events (0: 7, or 4 for runs of at most 64 steps)")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +137,7 @@ def main():
     # Kernel durations: HIP events on the launch stream around the kernels of every P-th step of the timed region (recording
     # and resolving them costs 12 us per step, 2.7 % of a step, so they are not put on every step; 7 is coprime to the
     # 240-step episode, so level-regeneration steps are sampled in proportion).
-    P = args.profile_every if args.profile_every > 0 else (1 if args.steps <= 64 else 7)
+    P = args.profile_every if args.profile_every > 0 else (7 if args.steps > 64 else 4 if args.steps >= 8 else 1)
     nsamp = 0
     sim.set_profiling(False)
     # the kernels a step launches: k_physics (its tail is the per-step reset) and, unless skipped, k_observe
