@@ -10,6 +10,14 @@ rank r simulates global worlds [r*16000, (r+1)*16000) (weak scaling).
 Prints ONE JSON line (rank 0) with the bench contract fields plus
   "roofline":     dominant kernel vs the HBM roofline (algorithmic bytes / HIP-event kernel time)
   "cpu_baseline": the CPU oracle (own restatement, NOT the Madrona CPU backend) on the host cores
+
+Two ways to get N ranks (the reference is single-GPU, src/mgr.hpp:18 `gpuID`; the ranks are this build's extension):
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` — RANK / LOCAL_RANK / WORLD_SIZE come
+    from the launcher;
+  * plain `python bench.py --gpus N` — with WORLD_SIZE unset the process becomes a LAUNCHER: it starts N copies of
+    itself (rank r pinned to device r), never touches a GPU itself, relays rank 0's JSON line and exits non-zero if
+    any rank failed.  A rank whose device does not exist fails loudly ("device r not visible") instead of the job
+    shrinking silently.
 """
 import argparse
 import json
@@ -42,7 +50,19 @@ def algorithmic_bytes(sim, A, kernel):
     return float(per_world.sum()), float(per_world.sum() / n)
 
 
-def cpu_baseline(seconds_budget=20.0):
+def csrc_fingerprint():
+    """First 12 hex digits of the SHA-256 over the kernel sources: ties a profiles/*_traffic.json to the build it measured."""
+    import hashlib
+    d = os.path.join(ROOT, "marl-hideandseek_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def cpu_baseline(seconds_budget=45.0, steps_of=1920):
     """Oracle timed on the host cores over a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
@@ -63,12 +83,98 @@ def cpu_baseline(seconds_budget=20.0):
         ref.step()
         act[:, 0:2] = rng.integers(-5, 5, size=(act.shape[0], 2))
         steps += 1
-        if time.time() - t0 > seconds_budget or steps >= 480:
+        if time.time() - t0 > seconds_budget or steps >= steps_of:
             break
     dt = time.time() - t0
     return {"value": nworlds * steps / dt, "unit": "world-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{nworlds} worlds x {steps} steps (scripts/cpu_benchmark.py args), own CPU restatement "
+            "steps": steps, "steps_of": steps_of, "complete": steps >= steps_of,
+            "sample": f"{nworlds} worlds x {steps} of {steps_of} steps (scripts/cpu_benchmark.py args: BASELINE configs[0]"
+                      f"{'' if steps >= steps_of else ', cut at the time budget'}), own CPU restatement "
                       f"(oracle/), {cores} threads over worlds; not the Madrona CPU backend"}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(nranks, argv):
+    """The launcher half of `bench.py --gpus N` (WORLD_SIZE unset): N child processes, one per GPU.  This process
+    imports neither torch nor the simulator and makes no HIP call.  Returns the exit code."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_WORLD_SIZE": str(nranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HS_BENCH_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # A rank that dies (no such device, a HIP error) must not leave the others waiting in a barrier for ever: poll, and
+    # once one has failed give the rest a few seconds, then end exactly the processes started here.
+    failed, deadline = [], None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0) and r not in failed:
+                failed.append(r)
+                deadline = deadline or time.time() + 10.0
+        if deadline and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    failed = [r for r, p in enumerate(procs) if p.returncode != 0]
+    if failed:
+        sys.stderr.write("bench.py launcher: rank(s) %s of %d failed (exit codes %s); no result line\n"
+                         % (failed, nranks, [procs[r].returncode for r in failed]))
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py launcher: rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def stub_rank(args, rank, local_rank, world_size):
+    """HS_BENCH_STUB=1 (tests/test_bench_launcher.py, no GPU): the rank plumbing of main() — process group, barrier,
+    max-over-ranks of the time, count of ranks that stepped, gather of per-rank times — around a sleep instead of the
+    simulator.  Never set by the driver; the line says "stub": true."""
+    import torch
+    import torch.distributed as dist
+    if world_size > 1:
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt_own = time.perf_counter() - t0
+    dt, stepped, per_rank = dt_own, 1, [dt_own]
+    if world_size > 1:
+        dist.barrier()
+        t = torch.tensor([dt_own], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([1], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        stepped = int(c.item())
+        g = [torch.zeros(1, dtype=torch.float64) for _ in range(world_size)]
+        dist.all_gather(g, torch.tensor([dt_own], dtype=torch.float64))
+        per_rank = [float(x.item()) for x in g]
+    if rank == 0:
+        print(json.dumps({"stub": True, "n_gpus": stepped, "world_size": world_size, "steps": args.steps,
+                          "ms_per_step": dt * 1e3 / max(args.steps, 1),
+                          "ms_per_step_per_rank": [x * 1e3 / max(args.steps, 1) for x in per_rank],
+                          "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")},
+                          "local_rank": local_rank, "worlds_per_gpu": args.worlds_per_gpu,
+                          "world_offsets": [r * args.worlds_per_gpu for r in range(world_size)]}), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -80,24 +186,42 @@ def main():
                     help="16000 = BASELINE configs[1] (default); 16384 = one rank of configs[3] (131072 worlds over 8 GPUs)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=45.0,
+                    help="time budget of the cpu_baseline leg (2000 worlds x 1920 steps take about 25 s on 16 threads)")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="steps between two steps that carry HIP events (0: 7, or 4 for runs of at most 64 steps)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    import torch
-    import gpu_hideseek
+    # `bench.py --gpus N` outside a launcher: become the launcher (before anything touches a GPU).
+    # (HS_BENCH_FORCE_LAUNCHER=1 sends --gpus 1 through the launcher too: the 1-GPU test of this path)
+    if (args.gpus > 1 or os.environ.get("HS_BENCH_FORCE_LAUNCHER") == "1") and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a GPU: the HIP path is the only execution path")
+    if world_size != args.gpus:
+        raise RuntimeError(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world_size} ranks")
+    if os.environ.get("HS_BENCH_STUB") == "1":
+        return stub_rank(args, rank, local_rank, world_size)
+
+    import numpy as np
+    import torch
+    import gpu_hideseek
+
     # Rehearsal switch for a one-GPU box: HS_BENCH_REHEARSE=1 maps every rank to GPU 0 and uses gloo for the barrier /
     # max-reduction (RCCL refuses two ranks on one device).  The driver's runs never set it.
     rehearse = os.environ.get("HS_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if local_rank >= ndev:
+        raise RuntimeError(f"rank {rank}: device {local_rank} not visible ({ndev} GPU(s) on this node); "
+                           f"--gpus {args.gpus} needs {args.gpus} devices")
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the HIP path is the only execution path")
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
@@ -143,43 +267,44 @@ def main():
     # the kernels a step launches: k_physics (its tail is the per-step reset) and, unless skipped, k_observe
     skip_obs = bool(args.flags & (1 << 16))
     kms = {"physics": 0.0} if skip_obs else {"physics": 0.0, "observe": 0.0}
-    overlapped = False
     barrier()
     t0 = time.perf_counter()
+    tprev = t0
+    step_s = []                        # host wall time of every step (a step blocks until its kernels are done)
     for i in range(args.steps):
         if i % P:
             one_step()
-            continue
-        sim.set_profiling(True)
-        one_step()
-        k = sim.last_step_kernel_ms()
-        sim.set_profiling(False)
-        nsamp += 1
-        kms["physics"] += k["physics"]
-        if not skip_obs:
-            overlapped = overlapped or k["observe"] < 0
-            kms["observe"] += max(k["observe"], 0.0)
+        else:
+            sim.set_profiling(True)
+            one_step()
+            k = sim.last_step_kernel_ms()
+            sim.set_profiling(False)
+            nsamp += 1
+            kms["physics"] += k["physics"]
+            if not skip_obs:
+                kms["observe"] += k["observe"]
+        tnow = time.perf_counter()
+        step_s.append(tnow - tprev)
+        tprev = tnow
     barrier()
     dt = time.perf_counter() - t0
-    obs_pass_steps = 0
-    if overlapped:
-        # Under the dependency schedule (HS_OVERLAP=1) k_observe runs beside k_physics and has no duration of its own in
-        # the timed region; its kernel time comes from an extra, untimed pass with the two kernels launched one after
-        # the other (same results).  k_physics' events above are from the timed region.
-        sim.set_overlap(False)
-        sim.set_profiling(True)
-        kms["observe"] = 0.0
-        obs_pass_steps = min(args.steps, 240)
-        for _ in range(obs_pass_steps):
-            one_step()
-            kms["observe"] += sim.last_step_kernel_ms()["observe"]
-        kms["observe"] *= nsamp / max(obs_pass_steps, 1)
-        sim.set_profiling(False)
-        sim.set_overlap(True)
+    dt_own = dt
+    stepped, per_rank_ms = 1, [dt_own / args.steps * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+        cdev = "cpu" if rehearse else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        c = torch.tensor([1], dtype=torch.int64, device=cdev)          # ranks that actually stepped
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        stepped = int(c.item())
+        g = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world_size)]
+        dist.all_gather(g, torch.tensor([dt_own], dtype=torch.float64, device=cdev))
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in g]
+
+    # A candidate pair beyond the LDS capacities spills to the slow path (counted), none is ever dropped: say so per run.
+    status = sim.device_status()
+    assert status["dropped_candidate_pairs"] == 0, f"broadphase candidate pairs were dropped: {status}"
 
     # Roofline position of the dominant kernel.  A step is two kernels: k_physics (persistent: movement / actions,
     # 4 XPBD substeps, rewards, per-step reset) and k_observe.  Durations are HIP events on the launch stream
@@ -195,18 +320,28 @@ def main():
                         "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS}
         assert 0.0 <= per_stage[n]["frac"] <= 1.0, f"roofline fraction of {n} out of range: {per_stage[n]}"
     dom = max(kms, key=lambda n: kms[n])
-    traffic = None
-    # PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh): the newest round's file
+    # HBM-side traffic cannot be measured inside this process (PMC counters need rocprofv3): it is read from the newest
+    # committed PMC run (tools/pmc.sh + tools/pmc_summary.py) and only when that run was made with THIS build of the
+    # kernels (fingerprint of csrc/); otherwise null.  The source is always named.
+    traffic, traffic_source = None, "none: no profiles/*_traffic.json"
     tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-    if tfiles and N == WORLDS_PER_GPU:
+    if tfiles and N == WORLDS_PER_GPU and args.flags == 0:
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1]))).get(dom, {}).get("hbm_bytes_per_step")
-        except Exception:
-            traffic = None
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1])))
+            if tj.get("csrc_sha") == csrc_fingerprint():
+                traffic = tj.get(dom, {}).get("hbm_bytes_per_step")
+                traffic_source = f"profiles/{tfiles[-1]} (rocprofv3 PMC passes of a 40-step run of this build, csrc {tj.get('csrc_sha')}; not this run)"
+            else:
+                traffic_source = f"dropped: profiles/{tfiles[-1]} was measured on other kernel sources (csrc {tj.get('csrc_sha')} != {csrc_fingerprint()})"
+        except Exception as e:
+            traffic_source = f"unreadable profiles/{tfiles[-1]}: {e}"
+    elif tfiles:
+        traffic_source = "none: the committed PMC run is for 16000 worlds, sim_flags 0"
     step_bytes, step_per_world = algorithmic_bytes(sim, A, "physics_only_step" if skip_obs else "step")
     step_ms = dt / args.steps * 1e3
     roofline = {"bound": "hbm", "kernel": per_stage[dom]["kernel"], "achieved": per_stage[dom]["achieved_GBps"],
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": per_stage[dom]["frac"], "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_kernel_ms": per_stage[dom]["avg_ms"],
                 "algorithmic_bytes_per_world_step": per_stage[dom]["algorithmic_bytes_per_world_step"],
                 "stages": per_stage,
@@ -217,18 +352,21 @@ def main():
                 "kernel_ms_per_step": {n: kms[n] / max(nsamp, 1) for n in kms},
                 "kernel_time_samples": {"every": P, "count": nsamp, "how": "HIP events on the launch stream around the kernels of "
                                         "every P-th step of the timed region"},
-                "schedule": ("k_observe beside k_physics, octets in finish order (dependency schedule); k_physics timed "
-                             "in the timed region, k_observe in an extra pass of %d sequential steps" % obs_pass_steps)
-                if overlapped else "k_physics then k_observe on one stream"}
+                "schedule": "k_physics then k_observe on one stream"}
 
     if rank == 0:
-        total_worlds = N * world_size
+        assert stepped == world_size, f"{stepped} of {world_size} ranks stepped"
+        total_worlds = N * stepped
         out = {
             "metric": "world-steps/sec (agent-steps/sec derived) at 16K worlds, 1/2/4/8 GPU",
             "value": total_worlds * args.steps / dt,
             "unit": "world-steps/s",
-            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": stepped, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_per_rank": per_rank_ms,
+            # host wall time per step on rank 0 (a step blocks until its kernels are done): the scatter of the run itself
+            "ms_per_step_percentiles": {k: float(np.percentile(np.asarray(step_s) * 1e3, q))
+                                        for k, q in (("min", 0), ("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N} worlds/GPU x {args.steps} steps, 2 hiders + 2 seekers, sim_flags={args.flags}, "
@@ -245,6 +383,7 @@ def main():
                                       if args.steps >= 240 else "partial episode"},
             "roofline": roofline,
         }
+        out["device_status"] = status
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         elif not args.no_cpu_baseline:
@@ -257,4 +396,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -48,7 +48,11 @@ def main():
         per[s] = {"launches": n, "fetch_KiB_per_launch_raw": tot / n, "write_KiB_per_launch": wtot / max(wn, 1),
                   "hbm_bytes_per_launch": tot / n * 1024.0 * fetch_factor + wtot / max(wn, 1) * 1024.0 * write_factor}
     phys = per.get("k_physics", {}).get("hbm_bytes_per_launch")       # one persistent kernel per step
-    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), bench.py --steps 40, %d worlds; summarised by tools/pmc_summary.py" % worlds,
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_fingerprint
+    res = {"csrc_sha": csrc_fingerprint(),          # the kernel sources this run measured (bench.py drops a stale file)
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), bench.py --steps 40, %d worlds; summarised by tools/pmc_summary.py" % worlds,
            "calibration": {"pattern": "one coalesced dword per lane, 512 MiB read + 512 MiB written (hs_debug_calibrate)",
                            "fetch_factor": fetch_factor, "write_factor": write_factor},
            "per_kernel": per,
