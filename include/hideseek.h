@@ -227,27 +227,23 @@ typedef struct hs_iface_entry {
 int32_t hs_train_interface(const hs_iface_entry **entries);
 
 /* Device-side conditions the reference has no channel for (it asserts or aborts).
- *   dropped_dd_pairs / dropped_static_pairs: broadphase candidate pairs beyond the per-world capacities (16 body-body,
- *     24 body-static per substep) that were discarded — the oracle discards the same ones, so parity cannot see it.
- *     Sticky totals since hs_create.  hs_step still returns HS_OK; hs_last_error() carries a warning.
- *   graphs_in_use: 1 when HS_GRAPH=1 took effect and steps are replayed as HIP graphs.
- *   sched_error: non-zero when a bounded device-side wait of the dependency schedule expired (k_observe waiting for a
- *     physics wave, or its gate): the blocking step that saw it returns HS_ERR_HIP, and so does the next call of an
- *     asynchronous entry point — stale observations are never handed over as HS_OK. */
+ *   spilled_dd_pairs / spilled_static_pairs: broadphase candidate pairs of a world beyond what the physics kernel keeps
+ *     in LDS per substep (16 body-body, 24 body-static).  They are NOT lost: they go through a global spill list sized
+ *     for the worst case (17 bodies: 136 pairs; 17 x 38 statics — the reference sizes for every entity too,
+ *     src/sim.cpp:1356-1361) and are tested and solved in the same order as every other pair, on a slower path; results
+ *     are identical to an unbounded solver.  Sticky totals since hs_create; a performance signal, not an error.
+ *   dropped_dd_pairs / dropped_static_pairs: candidate pairs discarded.  Always 0 (nothing can overflow the spill
+ *     lists); kept so that callers can assert it (bench.py, tools/train_config_bench.py do).
+ *   graphs_in_use: 1 when HS_GRAPH=1 took effect and steps are replayed as HIP graphs. */
 typedef struct hs_device_status {
     int64_t dropped_dd_pairs;
     int64_t dropped_static_pairs;
     int32_t graphs_in_use;
-    int32_t sched_error;
+    int32_t reserved;
+    int64_t spilled_dd_pairs;
+    int64_t spilled_static_pairs;
 } hs_device_status;
 int32_t hs_get_device_status(hs_sim *sim, hs_device_status *out);
-/* The dependency schedule between the two kernels of a step (k_observe beside k_physics, taking octets of worlds in
- * the order physics finishes them) is opt-in (1 here, or HS_OVERLAP=1 for every handle) and takes effect when the
- * whole batch is resident on the device (<= 64 worlds per CU); by default the kernels are launched one after the other.
- * Results are identical. */
-int32_t hs_set_overlap(hs_sim *sim, int32_t enabled);
-/* Test hook: plants `code` in the device-side sched_error word as an expired wait would. */
-int32_t hs_debug_inject_sched_error(hs_sim *sim, int32_t code);
 
 /* maxAgentsPerWorld (src/mgr.cpp:684). */
 int32_t hs_agents_per_world(const hs_sim *sim);

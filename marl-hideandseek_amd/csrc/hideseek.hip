@@ -45,20 +45,9 @@ struct hs_sim {
     bool initialised = false;
     bool use_graph = false;                // env HS_GRAPH=1: replay the step as HIP graphs (measured 2 % slower than two direct launches)
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};     // physics, observe
-    // Dependency schedule (opt-in: HS_OVERLAP=1 or hs_set_overlap): k_observe is launched on its own stream beside
-    // k_physics and takes octets in the order their physics wave finishes.  Off by default since k_observe takes under
-    // 0.1 ms: the agent-scope release every physics wave then needs (a write-back of its XCD's L2) and the slowdown of
-    // the physics waves that share a SIMD with k_observe cost more than the overlap hides.
-    bool overlap = false;
-    bool overlapped_last = false;          // the last launch used obs_stream
-    int slots = 0;                         // physics waves the device holds at once (8 per CU: LDS)
     hipStream_t step_stream = nullptr;     // the stream of the open step
     bool blocking_own_stream = false;      // HS_STREAM=own: hs_step uses the handle's stream as hs_step_begin does
     int step_idx = 0;                      // physics launches mod 3 (SimState::tickSum)
-    int gate_pct = 0;                      // k_observe starts when this share of the physics waves has finished (HS_GATE_PCT)
-    int sched_par = 0;                     // parity of the next overlapped step (finish lists are double-buffered)
-    hipStream_t obs_stream = nullptr;      // k_observe runs here, beside k_physics
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
     // Load balancing between the physics waves (hs_k_balance.h; HS_BALANCE=0 turns it off, HS_BALANCE_PERIOD sets the steps between deals)
     bool balance = true;
     int balance_period = 32, steps_since_balance = 0;
@@ -67,9 +56,7 @@ struct hs_sim {
     hipStream_t stream = nullptr;          // this handle's own stream: hs_init / hs_step / checkpoints run here
     hipEvent_t evIn = nullptr;             // orders `stream` after the device's legacy default stream (torch's writes to `action`)
     bool step_open = false;                // hs_step_begin without its hs_step_end
-    int *host_flag = nullptr;              // pinned, device-visible: set by a kernel when it bumps S.status (rare)
-    int status_cache[4] = {0, 0, 0, 0};    // last copy of S.status
-    volatile int32_t async_error = 0;      // a failed XLA custom call on this handle (hs_xla_*: the ABI has no status channel)
+    std::atomic<int32_t> async_error{0};   // a failed XLA custom call on this handle (hs_xla_*: the ABI has no status channel; XLA's thread)
 
     template <typename T> int dalloc(T **p, size_t n, int fill_byte = 0) {
         void *d = nullptr;
@@ -116,9 +103,8 @@ void launch_render(hs_sim *s, hipStream_t strm) {
                        (unsigned *)s->exports[HS_EXPORT_RGB].ptr, (int)d.dims[2], (int)d.dims[1]);
 }
 
-void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
+void launch_observe(hs_sim *s, hipStream_t strm) {
     hs::SimState S = s->S;
-    S.stepPar = step_par;
     if (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) return;
     struct RenderAfter {        // HS_FLAG_EXT_RENDER: the agent views are part of every step's observations
         hs_sim *s; hipStream_t strm;
@@ -135,30 +121,11 @@ void launch_observe(hs_sim *s, hipStream_t strm, int step_par = -1) {
 // One step = k_physics (movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results, reset: one
 // kernel, a wave per octet of 8 worlds, hs_k_physics.h) and k_observe.  Manager::init = k_reset then k_observe.
 // `stages`: 1 physics, 2 reset (init only), 4 observe.
-//
-// Dependency schedule: the physics waves are independent and finish at very different times (an octet with many
-// contacts takes up to 1.8 x the time of a quiet one), so towards the end of k_physics most of the chip is idle.
-// k_observe is therefore launched on its own stream right away; its workgroups take octets in the order k_physics
-// finishes them and fill the slots that finished waves leave.  Only when every physics wave is resident from the
-// start (octets <= 8 per CU): then none of them ever waits for a slot that a waiting k_observe workgroup holds, and
-// k_gate keeps k_observe from starting before all of them have been placed.
-int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7, bool allow_overlap = false,
-                      bool host_joins = false) {
+int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7) {
     hs::SimState S = s->S;
     const int N = S.N, noct = (N + hs::kTile - 1) / hs::kTile;
-    const bool skip_obs = (S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
-    // (8 slots of slack: k_gate and the first k_observe workgroups must never take a slot that a physics wave still needs)
-    const bool overlap = allow_overlap && s->overlap && !first && stages == 7 && !skip_obs && noct + 8 <= s->slots;
-    S.stepPar = overlap ? s->sched_par : -1;
     S.stepIdx = s->step_idx; if (!first && (stages & 1)) s->step_idx = (s->step_idx + 1) % 3;
-    s->overlapped_last = false;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
-    // (a blocking hs_step has synchronised everything before and joins the two streams on the host: cross-stream
-    // event waits cost tens of microseconds each)
-    if (overlap && !host_joins) {
-        HS_HIP(hipEventRecord(s->evFork, strm));
-        HS_HIP(hipStreamWaitEvent(s->obs_stream, s->evFork, 0));
-    }
     if (!first && (stages & 1)) {
         // 17 body slots x 8 worlds need a third round of 64 lanes only with 6 agents per world
         if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3(noct), dim3(hs::kPhysThreads), 0, strm, S);
@@ -168,20 +135,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
     if (first && (stages & 2)) hipLaunchKernelGGL(hs::k_reset, dim3((N + 31) / 32), dim3(32), 0, strm, S);     // half-filled waves: the generator diverges per world
     if (prof) HS_HIP(hipEventRecord(s->ev[2], strm));
-    if (overlap) {
-        hipLaunchKernelGGL(hs::k_gate, dim3(1), dim3(64), 0, s->obs_stream, S, noct, (int)((long long)noct * s->gate_pct / 100));
-        launch_observe(s, s->obs_stream, s->sched_par);
-        if (prof) HS_HIP(hipEventRecord(s->ev[3], s->obs_stream));
-        if (!host_joins) {
-            HS_HIP(hipEventRecord(s->evJoin, s->obs_stream));
-            HS_HIP(hipStreamWaitEvent(strm, s->evJoin, 0));
-        }
-        s->overlapped_last = true;
-        s->sched_par ^= 1;
-    } else {
-        if (stages & 4) launch_observe(s, strm);
-        if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
-    }
+    if (stages & 4) launch_observe(s, strm);
+    if (prof) HS_HIP(hipEventRecord(s->ev[3], strm));
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -221,13 +176,13 @@ int balance_worlds(hs_sim *s, hipStream_t strm) {
 // events between the graph launches.  It paid off while physics was ~40 launches per step; with the persistent
 // physics kernel a step is two launches and the direct launches are faster.  When capture or instantiation fails
 // the handle falls back to direct launches and hs_get_device_status reports graphs_in_use = 0.
-int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false) {
+int launch_step(hs_sim *s, hipStream_t strm, bool first) {
     if (!first && s->balance && ++s->steps_since_balance >= s->balance_period) {
         s->steps_since_balance = 0;
         int rc = balance_worlds(s, strm);
         if (rc != HS_OK) return rc;
     }
-    if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling, 7, true, host_joins);
+    if (first || !s->use_graph) return launch_step_eager(s, strm, first, s->profiling);
     const bool skip_obs = (s->S.flags & hs::FLAG_EXT_SKIP_OBSERVATIONS) != 0;
     const int ngraphs = skip_obs ? 1 : 2;
     if (!s->graph_exec[0]) {
@@ -258,20 +213,12 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first, bool host_joins = false
     return HS_OK;
 }
 
-// Device-side conditions (include/hideseek.h hs_device_status).  The kernels bump S.status and raise the pinned
-// host flag only when something happened, so the check after a step is one host-memory read.
+// A failure of an earlier asynchronous entry point (the XLA custom calls have no status channel) surfaces at the next call
+// that can report it.  Nothing here touches the device: the sticky counters of hs_get_device_status (candidate pairs
+// that took the spill path) are read only on request, so no step ever pays a blocking copy for them.
 int poll_status(hs_sim *s) {
-    if (s->async_error) {
-        const int32_t e = s->async_error; s->async_error = 0;
-        return fail(HS_ERR_HIP, "an XLA custom call on this simulator failed earlier with status " + std::to_string(e));
-    }
-    if (!s->host_flag || !*(volatile int *)s->host_flag) return HS_OK;
-    HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
-    if (s->status_cache[2] != 0)
-        return fail(HS_ERR_HIP, "device-side wait of the dependency schedule expired (sched_error " +
-                                std::to_string(s->status_cache[2]) + "): the observations of this step are incomplete");
-    g_err = "warning: broadphase candidate pairs beyond the per-world capacity were dropped (" +
-            std::to_string(s->status_cache[0]) + " body-body, " + std::to_string(s->status_cache[1]) + " body-static so far)";
+    const int32_t e = s->async_error.exchange(0);
+    if (e != 0) return fail(HS_ERR_HIP, "an XLA custom call on this simulator failed earlier with status " + std::to_string(e));
     return HS_OK;
 }
 
@@ -349,12 +296,10 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.xBoxObs, R * 9 * 17); HS_ALLOC(S.xRampObs, R * 2 * 14); HS_ALLOC(S.xVisAgents, R * 5);
     HS_ALLOC(S.xVisBoxes, R * 9); HS_ALLOC(S.xVisRamps, R * 2); HS_ALLOC(S.xLidar, R * 30);
     HS_ALLOC(S.xReward, R); HS_ALLOC(S.xGlobalPos, N * 34); HS_ALLOC(S.xEpisodeResult, N * 2);
-    { char *p; HS_ALLOC(p, N * hs::kMaxDDCand * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, N * hs::kMaxSCand * sizeof(hs::ManS)); S.wsSC = p; }
+    // (every possible pair of every world: 92 KB per world, 1.5 GB at 16 000 worlds, of which a step touches a few MB)
+    { char *p; HS_ALLOC(p, NP * hs::kAllDD * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, NP * hs::kAllSC * sizeof(hs::ManS)); S.wsSC = p; }
+    HS_ALLOC(S.spPair, NP * (hs::kAllDD + hs::kAllSC)); HS_ALLOC(S.spInfo, NP * hs::kSpInfoWords);
     HS_ALLOC(S.phaseTicks, 10 * (NP / hs::kTile) + 16 * 1024 + 16);     // + 1024 x 16 section counters of k_observe
-    { const size_t G = NP / hs::kTile;
-      if ((rc = s->dalloc(&S.doneList, 2 * G, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }
-      HS_ALLOC(S.doneTickets, 2); HS_ALLOC(S.startedCount, 2); }
-    S.stepPar = -1;
     HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N); HS_ALLOC(S.wallHist, N);
     if ((rc = s->dalloc(&S.slotHdr, NP, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }      // world id -1: empty slot
     HS_ALLOC(S.lidarSinCos, 60);
@@ -363,9 +308,6 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     { char *tmp; s->bal_tmp_bytes = (size_t)S.walls.kRows * NP * sizeof(float); HS_ALLOC(tmp, s->bal_tmp_bytes); s->bal_tmp = tmp; }
     HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
-    if (hipHostMalloc((void **)&s->host_flag, 64, hipHostMallocMapped) != hipSuccess) { s->host_flag = nullptr; hs_destroy(s); return fail(HS_ERR_HIP, "hipHostMalloc failed"); }
-    *s->host_flag = 0;
-    if (hipHostGetDevicePointer((void **)&S.hostFlag, s->host_flag, 0) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipHostGetDevicePointer failed"); }
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints
     {
         std::vector<int32_t> ones(N, 1), neg(AG * NP, -1), ident(NP);
@@ -382,17 +324,11 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
         if (hipEventCreate(&e) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "hipEventCreate failed"); }
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
-    if (const char *e = getenv("HS_OVERLAP")) s->overlap = atoi(e) != 0;
     if (const char *e = getenv("HS_STREAM")) s->blocking_own_stream = std::strcmp(e, "own") == 0;
-    if (const char *e = getenv("HS_GATE_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) s->gate_pct = v; }
     if (const char *e = getenv("HS_BALANCE")) s->balance = atoi(e) != 0;
     if (const char *e = getenv("HS_BALANCE_PERIOD")) { const int v = atoi(e); if (v > 0) s->balance_period = v; }
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->gpu_id) == hipSuccess) s->slots = 8 * prop.multiProcessorCount; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->obs_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
+        hipEventCreateWithFlags(&s->evIn, hipEventDisableTiming) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "stream/event creation failed"); }
     S.wbeg = 0; S.wcnt = (int)N;
     hipLaunchKernelGGL(hs::k_lidar_table, dim3(1), dim3(64), 0, s->stream, S);
     if (hipStreamSynchronize(s->stream) != hipSuccess) { hs_destroy(s); return fail(HS_ERR_HIP, "k_lidar_table failed"); }
@@ -435,12 +371,8 @@ void hs_destroy(hs_sim *s) {
     hipDeviceSynchronize();
     for (void *p : s->allocs) hipFree(p);
     for (auto &e : s->ev) if (e) hipEventDestroy(e);
-    if (s->evFork) hipEventDestroy(s->evFork);
-    if (s->evJoin) hipEventDestroy(s->evJoin);
-    if (s->obs_stream) hipStreamDestroy(s->obs_stream);
     if (s->evIn) hipEventDestroy(s->evIn);
     if (s->stream) hipStreamDestroy(s->stream);
-    if (s->host_flag) hipHostFree(s->host_flag);
     for (auto &e : s->graph_exec) if (e) hipGraphExecDestroy(e);
     delete s;
 }
@@ -480,7 +412,7 @@ int step_begin(hs_sim *s, bool own_stream) {
     int rc = HS_OK;
     s->step_stream = own_stream ? s->stream : nullptr;
     if (own_stream) rc = order_after_default_stream(s);
-    if (rc == HS_OK) rc = launch_step(s, s->step_stream, false, true);
+    if (rc == HS_OK) rc = launch_step(s, s->step_stream, false);
     if (rc != HS_OK) return rc;
     s->step_open = true;
     return HS_OK;
@@ -495,13 +427,10 @@ int32_t hs_step_end(hs_sim *s) {
     s->step_open = false;
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     HS_HIP(hipStreamSynchronize(s->step_stream));
-    if (s->overlapped_last) HS_HIP(hipStreamSynchronize(s->obs_stream));
     if (s->profiling) {
         HS_HIP(hipEventElapsedTime(&s->last_ms[0], s->ev[0], s->ev[1]));
         HS_HIP(hipEventElapsedTime(&s->last_ms[1], s->ev[1], s->ev[2]));
-        // under the dependency schedule k_observe runs beside k_physics on another stream: it has no duration of its own
-        if (s->overlapped_last) s->last_ms[2] = -1.f;
-        else HS_HIP(hipEventElapsedTime(&s->last_ms[2], s->ev[2], s->ev[3]));
+        HS_HIP(hipEventElapsedTime(&s->last_ms[2], s->ev[2], s->ev[3]));
     }
     return poll_status(s);
 }
@@ -699,7 +628,7 @@ void xla_call(int32_t (*FN)(hs_sim *, void *, void **), void *stream, void **buf
     hs_sim *s = nullptr;
     if (opaque && opaque_len == sizeof(s)) memcpy(&s, opaque, sizeof(s));
     const int32_t rc = s ? FN(s, stream, buffers) : (int32_t)HS_ERR_INVALID_ARG;
-    if (rc != HS_OK) { g_xla_status.store(rc); if (s) s->async_error = rc; }
+    if (rc != HS_OK) { g_xla_status.store(rc); if (s) s->async_error.store(rc); }
 }
 }  // namespace
 void hs_xla_init(void *stream, void **buffers, const char *opaque, size_t opaque_len) { xla_call(hs_jax_init, stream, buffers, opaque, opaque_len); }
@@ -841,25 +770,14 @@ int32_t hs_get_device_status(hs_sim *s, hs_device_status *out) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     HS_HIP(hipDeviceSynchronize());
-    HS_HIP(hipMemcpy(s->status_cache, s->S.status, sizeof(s->status_cache), hipMemcpyDeviceToHost));
-    out->dropped_dd_pairs = s->status_cache[0];
-    out->dropped_static_pairs = s->status_cache[1];
+    int st[4];
+    HS_HIP(hipMemcpy(st, s->S.status, sizeof(st), hipMemcpyDeviceToHost));
+    out->spilled_dd_pairs = st[0];
+    out->spilled_static_pairs = st[1];
+    out->dropped_dd_pairs = 0;             // nothing can overflow the spill lists (hs_k_physics.h: sized for every pair)
+    out->dropped_static_pairs = 0;
     out->graphs_in_use = (s->use_graph && s->graph_exec[0]) ? 1 : 0;
-    out->sched_error = s->status_cache[2];
-    return HS_OK;
-}
-
-int32_t hs_set_overlap(hs_sim *s, int32_t enabled) {
-    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
-    s->overlap = enabled != 0;
-    return HS_OK;
-}
-
-int32_t hs_debug_inject_sched_error(hs_sim *s, int32_t code) {
-    if (!s) return fail(HS_ERR_INVALID_ARG, "null sim");
-    HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    HS_HIP(hipMemcpy(s->S.status + 2, &code, sizeof(code), hipMemcpyHostToDevice));
-    if (code != 0) *s->host_flag = 1;
+    out->reserved = 0;
     return HS_OK;
 }
 

@@ -238,10 +238,10 @@ HSD bool collide_hull_plane(const HullRef &A, V3 pn, float pd, RawManifold &m) {
 }
 
 // The ground-manifold form of collide_hull_plane: same vertex order, same selection and the same expressions, but
-// it keeps per contact only what the ground solve reads — the vertex index and the plane offset dot(pB, n) with
-// n = -pn — instead of the points (this runs for every body in every substep).  Returns np; idx packs 3 bits per
-// contact.
-HSD int ground_manifold(const HullRef &A, V3 pn, float pd, int *idx, float off[4]) {
+// it keeps per contact only what the ground solve reads — the vertex index (the plane offset dot(pB, n) of the ground
+// plane is a signed zero: hs_k_physics.h BodyReg) — instead of the points (this runs for every body in every substep).
+// Returns np; idx packs 3 bits per contact.
+HSD int ground_manifold(const HullRef &A, V3 pn, float pd, int *idx) {
     int np = 0, vi = 0; float depth[4] = {0.f, 0.f, 0.f, 0.f};
     const int nv = hull_nv(A);
     const V3 n = -pn;
@@ -252,7 +252,6 @@ HSD int ground_manifold(const HullRef &A, V3 pn, float pd, int *idx, float off[4
         float dist = dot(pn, v) - pd;
         if (!(dist < 0.f)) continue;
         float dep = -dist;
-        V3 pb = v - pn * dist;
         int slot;
         if (np < 4) { slot = np; np++; }
         else {
@@ -262,10 +261,9 @@ HSD int ground_manifold(const HullRef &A, V3 pn, float pd, int *idx, float off[4
             if (!(dep > depth[mi])) continue;
             slot = mi;
         }
-        const float o = dot(pb, n);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k == slot) { depth[k] = dep; off[k] = o; vi = (vi & ~(7 << (3 * k))) | (i << (3 * k)); }
+            if (k == slot) { depth[k] = dep; vi = (vi & ~(7 << (3 * k))) | (i << (3 * k)); }
     }
     *idx = vi;
     return np;

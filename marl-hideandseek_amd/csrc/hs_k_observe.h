@@ -115,32 +115,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
 #endif
     // blocks b, b + 8, ..., b + 56 (same XCD under round-robin placement) take the 8 worlds of one octet
     const int blk = blockIdx.x;
-    int oct = ((blk >> 6) << 3) + (blk & 7);
+    const int oct = ((blk >> 6) << 3) + (blk & 7);
     if (oct >= (S.N + kTile - 1) / kTile) return;        // (the grid covers whole groups of 8 octets)
-    if (S.stepPar >= 0) {
-        // Dependency schedule (hideseek.hip launch_step): `oct` counts finished octets — this workgroup takes a world
-        // of the oct-th octet whose physics wave FINISHES, and waits for it: one relaxed poll loop by one lane (bounded,
-        // so that a bug cannot hang the GPU), one agent-scope acquire, then the barrier.  Every physics wave is
-        // resident before this kernel starts (k_gate) and never waits for anything, so the wait always ends.
-        __shared__ int sh_oct;
-        const int noct = (S.N + kTile - 1) / kTile;
-        if (tid == 0) {
-            const int *slot = &S.doneList[S.stepPar * noct + oct];
-            int v = -1;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v >= 0) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-            if (v < 0) { S.status[2] = 1; *S.hostFlag = 1; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            sh_oct = v;
-        }
-        __syncthreads();
-        oct = sh_oct;
-        if (oct < 0) return;
-    }
     const int p = oct * kTile + ((blk >> 3) & 7);       // slot in the tiled columns
     // the world that lives there and its scalars (exports are indexed by world id): one load, issued beside the
     // column loads

@@ -37,6 +37,18 @@ constexpr int kMaxItems = kTile * (kMaxDDCand + kMaxSCand);        // convex-tes
 constexpr int kLdsWalls = 32;                      // walls per world staged in LDS for the broadphase (a world has
                                                    // 4..34; the rare ones beyond 32 are read from global memory)
 static_assert(kMaxSCand <= 32 && kMaxDDCand <= 16, "accepted-manifold masks are one word per world");
+// Candidate pairs of a world beyond the LDS capacities (kMaxDDCand / kMaxSCand) are NOT dropped: they spill.  The
+// reference has no cap below its entity count (src/sim.cpp:1356-1361), so the global workspace holds a manifold for
+// EVERY possible pair of a world — 17 bodies: 136 body-body pairs; 17 x (36 walls + 2 extra planes) body-static pairs —
+// indexed by the pair's place in the world's candidate order (the oracle's order).  Places below the capacity are the
+// fast path (LDS lists, lane-parallel solve); a place at or beyond it has its pair code in S.spPair and is tested and
+// solved after the fast ones of its kind, one after the other — which IS the oracle's order, because candidates are
+// generated in pair order (body-body) and per body in candidate order (statics).  Rare (two pairs in 15 M world-steps
+// of the training configuration), counted in S.status, bit-identical to the unbounded oracle
+// (libhideseek_smallcap.so runs every pair but the first through this path: tests/test_gpu_status.py).
+constexpr int kAllDD = kNumDSlots * (kNumDSlots - 1) / 2;                 // 136
+constexpr int kAllSC = kNumDSlots * (kMaxWalls + kMaxPlanes - 1);         // 646
+constexpr int kSpInfoWords = kNumDSlots + 1;      // S.spInfo per world: totals (dd | sc << 16), then per body: first spilled static | count << 16
 
 // ---- the octet's resident working set (LDS) ----
 // Every column is [row][world of the octet] exactly like its block in HBM (hs_state.h Col), so loading and storing
@@ -78,6 +90,7 @@ struct alignas(16) OctRes {
     unsigned int wallSeen[kTile];               // bit s: body slot s had a wall / extra-plane manifold (previous step's while the
                                                 // body list is built, then this step's: SimState::wallHist)
     unsigned char numWalls[kTile], numPlanes[kTile], ndd[kTile], nsc[kTile], seen[kTile], hasGrab[kTile];
+    unsigned char spill[kTile];                 // this substep: bit 0 body-body, bit 1 body-static candidates beyond the LDS capacity
     int wid[kTile];                             // world id of each slot of the octet (SimState::worldOfSlot), -1 = empty slot
 };
 static_assert(sizeof(OctRes) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
@@ -178,12 +191,17 @@ struct ResGeom {
     HSD float g_plane(int p, int c) const { return S.planes(c * kMaxPlanes + p, w); }
 };
 
-// What a body's lane keeps in registers for the whole step: which body it is, the agent's force / torque, and the
+// What a body's lane keeps in registers for the whole step: which body it is and the
 // ground-plane manifold of the current substep (up to 4 deepest vertices, hs_collide.h ground_manifold).
+constexpr float kGroundOff = 0.f;
 struct BodyReg {
-    V3 force; float torque;  // ExternalForce / ExternalTorque.z (agents)
     int np, vidx;            // ground manifold: contact count, 3 bits of vertex index per contact
-    float off[4], lam[4];    // plane offsets, accumulated normal multipliers
+    float lam[4];            // accumulated normal multipliers
+    // (No plane offsets dot(pB, n) per contact: plane 0 is the ground n = (0, 0, 1), d = 0 in every level — makePlane,
+    // level_gen.cpp:68-71, 294-295 and each debug level — and for that plane the offset is a signed zero in exact IEEE
+    // arithmetic: pB = v - pn * dist with dist = pn.v - 0 = v.z gives pB.z = +0, and dot(pB, -pn) sums products with
+    // zero.  `x - (+-0)` is x for every x but a zero, whose sign no comparison or sum below can see.  kGroundOff stands for
+    // it; the oracle computes the offset from the plane it is given and gets the same bits.)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -207,9 +225,18 @@ HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
 // ------------------------------------------------------------------------------------------
 // Start of a substep for one body: remember the pose, semi-implicit Euler step (gravity, agent force and
 // torque, gyroscopic term), refresh the hull AABB and the ground-plane manifold (registers of the body's lane).
-HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta) {
+// `aforce`: the octet's block of S.aforce (ExternalForce xyz + ExternalTorque z of the agents, written by phase_pre);
+// read here, four times per step by the agents' lanes, rather than kept in four registers for the whole step — the step
+// sits at its register budget.
+HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta, const float *aforce) {
     const int obj = meta_obj(meta);
     const bool dyn = meta_resp(meta) == RESP_DYNAMIC;
+    V3 force = {0.f, 0.f, 0.f}; float torque = 0.f;
+    if (dyn && slot >= kAgentSlot0) {
+        const float *f = aforce + (slot - kAgentSlot0) * kTile + g;
+        force = {f[0 * kMaxAgents * kTile], f[1 * kMaxAgents * kTile], f[2 * kMaxAgents * kTile]};
+        torque = f[3 * kMaxAgents * kTile];
+    }
     V3 pos = rld3(R.pos, slot, g); Q rot = rld4(R.rot, slot, g);
     rst3(R.ppos, slot, g, pos); rst4(R.prot, slot, g, rot);
     if (dyn) {
@@ -217,10 +244,10 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta) {
         const float h = kSubstepH;
         const float invM = obj_inv_mass(obj);
         const V3 invI = obj_inv_inertia(obj);
-        lin = lin + (b.force * invM + V3{0.f, 0.f, kGravityZ}) * h;
+        lin = lin + (force * invM + V3{0.f, 0.f, kGravityZ}) * h;
         pos = pos + lin * h;
         Q qi = qinv(rot);
-        V3 wloc = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, b.torque});
+        V3 wloc = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, torque});
         const V3 I = obj_inertia(obj);            // 1 / invI per axis, 0 where invI is 0
         V3 Iw = mulc(I, wloc);
         wloc = wloc + mulc(invI, tl - cross(wloc, Iw)) * h;
@@ -239,7 +266,7 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta) {
     for (int j = 0; j < 4; ++j) b.lam[j] = 0.f;
     if (dyn && R.numPlanes[g] >= 1) {
         const V3 pn = {R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
-        b.np = ground_manifold(hb, pn, R.plane0[3][g], &b.vidx, b.off);
+        b.np = ground_manifold(hb, pn, R.plane0[3][g], &b.vidx);
     }
 }
 
@@ -248,7 +275,7 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta) {
 // owns body slots l, l + 8, l + 16.  Also builds the octet's work list of convex tests.  Returns the number of
 // box-only items in .x and of items that involve a ramp (wedge hull) in .y; the ramp items start at the next
 // multiple of 32 so that most rounds of the convex test run the box code only.
-struct ItemCounts { int nbox, nwedge; };
+struct ItemCounts { int nbox, nwedge; bool anySpill; };
 template <int JB>            // body slots per lane: 2 covers 16 slots (<= 5 agents), 3 all 17
 HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
     constexpr int G = 8;
@@ -326,12 +353,13 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
-        if (add[jb] != cdd || asc[jb] != csc) {      // beyond the capacity: dropped (as the CPU restatement does), and counted
-            if (add[jb] != cdd) atomicAdd(&S.status[0], cdd - add[jb]);
-            if (asc[jb] != csc) atomicAdd(&S.status[1], csc - asc[jb]);
-            *S.hostFlag = 1;
-        }
+        if (add[jb] != cdd) atomicAdd(&S.status[0], cdd - add[jb]);      // beyond the capacity: the spill path, counted
+        if (asc[jb] != csc) atomicAdd(&S.status[1], csc - asc[jb]);
     }
+    const bool spillDD = tot_dd > kMaxDDCand, spillSC = tot_sc > kMaxSCand;
+    const bool anySpill = __ballot(spillDD || spillSC) != 0ull;
+    unsigned short *const spPair = S.spPair + (size_t)(S.wbeg + g) * (kAllDD + kAllSC);
+    int *const spInfo = S.spInfo + (size_t)(S.wbeg + g) * kSpInfoWords;
     // ---- the octet's work list: box-only items from the front, items with a ramp behind them (from a multiple of 32)
     int n_wedge = 0;
 #pragma unroll
@@ -344,6 +372,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
     const int n_box = tot_items - n_wedge;
     const int inc_box = scan64_incl(n_box), inc_wedge = scan64_incl(n_wedge);
     ItemCounts ic;
+    ic.anySpill = anySpill;
     ic.nbox = __builtin_amdgcn_readlane(inc_box, 63); ic.nwedge = __builtin_amdgcn_readlane(inc_wedge, 63);
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     int ibox = inc_box - n_box, iwedge = wedge0 + inc_wedge - n_wedge;
@@ -360,6 +389,11 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
             if (ramp || (j >= kRampSlot0 && j < kRampSlot0 + kMaxRamps)) R.u.sat.items[iwedge++] = item; else R.u.sat.items[ibox++] = item;
             ++i;
         }
+        while (mm) {                      // (beyond the capacity: the pair's code goes to the spill list, at its place)
+            const int j = __ffs(mm) - 1; mm &= mm - 1;
+            spPair[bdd[jb] + i] = (unsigned short)pair_pack(slot, j);
+            ++i;
+        }
         // oracle order inside a body: extra planes first, then walls by index; the body's candidates
         // occupy the contiguous range [bsc, bsc + asc) of the world's list
         unsigned long long sm = (s_mask[jb] >> kMaxWalls) | (s_mask[jb] << (64 - kMaxWalls) >> (64 - kMaxWalls) << kMaxPlanes); i = 0;
@@ -371,15 +405,194 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
             if (ramp) R.u.sat.items[iwedge++] = item; else R.u.sat.items[ibox++] = item;
             ++i;
         }
+        const int nspill = sm ? __popcll(sm) : 0;
+        while (sm) {
+            const int bit = __ffsll((long long)sm) - 1; sm &= sm - 1;
+            const int k = bit < kMaxPlanes ? kMaxWalls + bit : bit - kMaxPlanes;
+            spPair[kAllDD + bsc[jb] + i] = (unsigned short)pair_pack(slot, k);
+            ++i;
+        }
+        if (spillSC && slot < kNumDSlots) spInfo[1 + slot] = nspill ? ((bsc[jb] + asc[jb]) | (nspill << 16)) : 0;
         if (slot < NS) R.scInfo[slot][g] = (unsigned short)(asc[jb] > 0 ? (bsc[jb] | (asc[jb] << 8)) : 0);
     }
     if (l == 0) {
+        R.spill[g] = (unsigned char)((spillDD ? 1 : 0) | (spillSC ? 2 : 0));
+        if (spillDD || spillSC) spInfo[0] = tot_dd | (tot_sc << 16);
         R.ndd[g] = (unsigned char)min(tot_dd, kMaxDDCand); R.nsc[g] = (unsigned char)min(tot_sc, kMaxSCand);
         // what k_balance sorts the worlds by: candidate pairs are where an octet's time differs from another's
         if (R.wid[g] >= 0 && tot_dd + tot_sc > 0) S.loadAcc[R.wid[g]] += tot_dd + tot_sc;
     }
     wave_sync();
     return ic;
+}
+
+// ------------------------------------------------------------------------------------------
+// The SPILL PATH: candidate pairs beyond the LDS capacities.  Cold code behind wave-uniform branches.
+// The step's hot path sits exactly at the 256-register budget of two waves per SIMD, and any code that shares a
+// function with it — even behind a branch that is never taken — moves its register allocation.  So the rest of a substep
+// exists TWICE (substep_rest<ROUNDS, SPILL>): the fast instantiation contains nothing of what follows, and the
+// instantiation with SPILL is entered, after the broadphase, only for a substep in which a world of the octet spills.
+#define HS_COLD __device__ __forceinline__
+struct SpillCtx {
+    const float *walls, *planes;         // the tiled columns (hs_state.h Col)
+    ManDD *wsDD; ManS *wsSC; unsigned short *spPair; int *spInfo;
+    int wbeg;
+};
+HSD SpillCtx spill_ctx(const SimState &S) { return {S.walls.p, S.planes.p, (ManDD *)S.wsDD, (ManS *)S.wsSC, S.spPair, S.spInfo, S.wbeg}; }
+
+// Convex tests of the spilled pairs: world by world, body-body then body-static, 32 pairs per trip, two lanes per pair
+// for the axis search (sat_axes) and the pair's first lane for the contact generation right away (no compaction: this
+// is the rare path).  Every spilled pair gets a record at its place of the workspace; np = 0 says "no manifold".
+HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
+    OctRes &R = *Rp;
+    const int lane = threadIdx.x & 63;
+    const bool hi = (lane & 1) != 0;
+    const Col<float, 4 * kMaxWalls> walls = {const_cast<float *>(c.walls)};
+    const Col<float, 4 * kMaxPlanes> planes = {const_cast<float *>(c.planes)};
+#pragma unroll 1
+    for (int g = 0; g < kTile; ++g) {
+        const int fl = __builtin_amdgcn_readfirstlane((int)R.spill[g]);
+        if (fl == 0) continue;
+        const int w = c.wbeg + g;
+        const int tot = __builtin_amdgcn_readfirstlane(c.spInfo[(size_t)w * kSpInfoWords]);
+#pragma unroll 1
+        for (int kind = 0; kind < 2; ++kind) {
+            if ((fl & (1 << kind)) == 0) continue;
+            const bool isdd = kind == 0;
+            const int n = isdd ? tot & 0xffff : tot >> 16;
+#pragma unroll 1
+            for (int base = isdd ? kMaxDDCand : kMaxSCand; base < n; base += kClipLanes) {
+                const int kk = base + (lane >> 1);
+                if (kk < n) {
+                    const int pair = c.spPair[(size_t)w * (kAllDD + kAllSC) + (isdd ? 0 : kAllDD) + kk];
+                    const int a = pair_a(pair), bsel = pair_b(pair);
+                    const int oa = meta_obj(R.meta[a][g]);
+                    const V3 pa = rld3(R.pos, a, g);
+                    const Q qa = rld4(R.rot, a, g);
+                    ManDD *const md = c.wsDD + (size_t)w * kAllDD + kk;
+                    ManS *const ms = c.wsSC + (size_t)w * kAllSC + kk;
+                    RawManifold raw;
+                    raw.np = 0;
+                    bool plane = false;
+                    if (!isdd && bsel >= kMaxWalls) {           // extra planes (debug levels only): hull against plane
+                        const int p = bsel - kMaxWalls;
+                        const V3 pn = {planes(0 * kMaxPlanes + p, w), planes(1 * kMaxPlanes + p, w), planes(2 * kMaxPlanes + p, w)};
+                        plane = true;
+                        if (!hi && !collide_hull_plane(hull_ref_body(oa, pa, qa), pn, planes(3 * kMaxPlanes + p, w), raw)) raw.np = 0;
+                    } else {
+                        const HullSrc ha = hull_src_body(oa, pa, qa);
+                        const HullSrc hb = isdd ? hull_src_body(meta_obj(R.meta[bsel][g]), rld3(R.pos, bsel, g), rld4(R.rot, bsel, g))
+                                                : hull_src_wall(walls(0 * kMaxWalls + bsel, w), walls(1 * kMaxWalls + bsel, w),
+                                                                walls(2 * kMaxWalls + bsel, w), walls(3 * kMaxWalls + bsel, w));
+                        const AxisResult res = sat_axes(ha, hb, hi);
+                        const ClipBuf cb = {R.u.sat.clip, lane >> 1};
+                        if (!hi && res.code != 0 && !sat_contact(ha, hb, res, cb, raw)) raw.np = 0;
+                    }
+                    if (!hi) {
+                        const int ob = isdd ? meta_obj(R.meta[bsel][g]) : plane ? OBJ_PLANE : OBJ_WALL;
+                        const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
+                        const Q qai = qinv(qa);
+                        if (isdd) {
+                            md->a = a; md->b = bsel; md->np = raw.np; md->muS = muS; md->muD = muD;
+                            st3(md->n, raw.n);
+                            const V3 pb = rld3(R.pos, bsel, g);
+                            const Q qbi = qinv(rld4(R.rot, bsel, g));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < raw.np) {
+                                    st3(md->rA[j], qrot(qai, raw.pA[j] - pa)); st3(md->rB[j], qrot(qbi, raw.pB[j] - pb));
+                                    md->lam[j] = 0.f;
+                                }
+                        } else {
+                            ms->np = raw.np; ms->muS = muS; ms->muD = muD;
+                            st3(ms->n, raw.n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < raw.np) {
+                                    st3(ms->rA[j], plane ? hull_local_vertex(oa, raw.vidx[j]) : qrot(qai, raw.pA[j] - pa));
+                                    ms->offB[j] = dot(raw.pB[j], raw.n); ms->lam[j] = 0.f;
+                                }
+                        }
+                    }
+                }
+                wave_sync();            // (the clip scratch of this trip is free again)
+            }
+        }
+    }
+    mem_sync();
+}
+
+// The spilled body-body manifolds of a world, one after the other on ONE lane: the oracle's loop
+// (solve_manifold_positions / solve_manifold_velocities), which the lane-pair form of phase_dd reproduces bit for bit.
+// (World by world in a wave-uniform loop, here and below: the addresses into the large per-world workspaces are then
+// scalar arithmetic.  Per-lane 64-bit pointers would be hoisted to the top of the kernel as loop invariants and
+// spilled to scratch memory there — the step's hot path sits exactly at the 256-register budget of two waves per SIMD.)
+template <bool POS>
+HS_COLD void spill_dd(SpillCtx c, OctRes *Rp) {
+    OctRes &R = *Rp;
+#pragma unroll 1
+    for (int g = 0; g < kTile; ++g) {
+        if ((__builtin_amdgcn_readfirstlane((int)R.spill[g]) & 1) == 0) continue;
+        const int w = c.wbeg + g;
+        const int nall = __builtin_amdgcn_readfirstlane(c.spInfo[(size_t)w * kSpInfoWords]) & 0xffff;
+        if (threadIdx.x == 0) {
+#pragma unroll 1
+            for (int k = kMaxDDCand; k < nall; ++k) {
+                ManDD *const m = c.wsDD + (size_t)w * kAllDD + k;       // (read field by field: a private copy indexed by j would live in scratch memory)
+                const int np = m->np;
+                if (np <= 0) continue;
+                const int ba = m->a, bb = m->b;
+                BodyS Ab, Bb;
+                rbody_load(R, g, ba, Ab); rbody_load(R, g, bb, Bb);
+                const V3 n = ld3(m->n);
+                const float mu = POS ? m->muS : m->muD;
+#pragma unroll 1
+                for (int j = 0; j < np; ++j) {
+                    const float lamj = m->lam[j];
+                    if (POS) m->lam[j] = lamj + solve_point_position<true>(Ab, Bb, n, ld3(m->rA[j]), ld3(m->rB[j]), 0.f, mu);
+                    else solve_point_velocity<true>(Ab, Bb, n, ld3(m->rA[j]), ld3(m->rB[j]), lamj, mu);
+                }
+                if (POS) { rbody_store_pose(R, g, ba, Ab); rbody_store_pose(R, g, bb, Bb); }
+                else { rbody_store_vel(R, g, ba, Ab); rbody_store_vel(R, g, bb, Bb); }
+                wave_sync();
+            }
+        }
+    }
+}
+
+// The spilled static manifolds: a lane per body of the world walks the body's in order, after the body's ground manifold
+// and its static manifolds of the fast path — the oracle's order per body.
+template <bool POS>
+HS_COLD void spill_static(SpillCtx c, OctRes *Rp, int NS) {
+    OctRes &R = *Rp;
+#pragma unroll 1
+    for (int g = 0; g < kTile; ++g) {
+        if ((__builtin_amdgcn_readfirstlane((int)R.spill[g]) & 2) == 0) continue;
+        const int w = c.wbeg + g;
+        const int slot = threadIdx.x;
+        if (slot >= NS) continue;
+        const int info = c.spInfo[(size_t)w * kSpInfoWords + 1 + slot];
+        const int first = info & 0xffff, cnt = info >> 16;
+        if (cnt == 0) continue;
+        BodyS me, none;
+        rbody_load(R, g, slot, me);
+#pragma unroll 1
+        for (int k = first; k < first + cnt; ++k) {
+            ManS *const m = c.wsSC + (size_t)w * kAllSC + k;
+            const int np = m->np;
+            if (np <= 0) continue;
+            body_refresh_inertia(me);
+            const V3 n = ld3(m->n);
+            const float mu = POS ? m->muS : m->muD;
+#pragma unroll 1
+            for (int j = 0; j < np; ++j) {
+                const float lamj = m->lam[j];
+                if (POS) m->lam[j] = lamj + solve_point_position<false>(me, none, n, ld3(m->rA[j]), V3{0.f, 0.f, 0.f}, m->offB[j], mu);
+                else solve_point_velocity<false>(me, none, n, ld3(m->rA[j]), V3{0.f, 0.f, 0.f}, lamj, mu);
+            }
+        }
+        if (POS) rbody_store_pose(R, g, slot, me); else rbody_store_vel(R, g, slot, me);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -434,7 +647,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
                     m.lam[j] = 0.f;
                 }
                 if (toLds) { __builtin_memcpy(mw, &m, sizeof(m)); mkind = 1; mkk = kk; mg = g; mpair = pair; }
-                else { ((ManDD *)S.wsDD + (size_t)w * kMaxDDCand)[kk] = m; wroteGlobal = true; }
+                else { ((ManDD *)S.wsDD + (size_t)w * kAllDD)[kk] = m; wroteGlobal = true; }
                 atomicOr(&R.ddAcc[g], 1u << kk);
             } else {
                 ManS m;
@@ -447,7 +660,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
                     m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                 }
                 if (toLds) { __builtin_memcpy(mw, &m, sizeof(m)); mkind = 2; mkk = kk; mg = g; mpair = pair; }
-                else { ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m; wroteGlobal = true; }
+                else { ((ManS *)S.wsSC + (size_t)w * kAllSC)[kk] = m; wroteGlobal = true; }
                 atomicOr(&R.scAcc[g], 1u << kk);
             }
         }
@@ -471,6 +684,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
 }
 // Returns whether any manifold of the substep lies in the global workspace (wave-uniform): only then do the solver
 // phases have to wait for global memory at all.
+template <bool SPILL>
 HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     const int lane = threadIdx.x & 63;
@@ -487,6 +701,9 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
     // rounds over the box-only items, 2 lanes per pair and 32 pairs per round, then over the items with a wedge, 16 lanes
     // per pair and 4 pairs per round (sat_axes_wide); `lead`: the lane of a pair that files its result
     const int boxRounds = (ic.nbox + kClipLanes - 1) / kClipLanes, wedgeRounds = (ic.nwedge + 3) / 4;
+    // (pairs beyond the LDS capacities, if any world of the octet has them: tested and turned into manifolds first, while
+    // the clip buffers are free)
+    if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_sat(spill_ctx(S), &R); usedGlobal = true; }
     for (int round = 0; round < boxRounds + wedgeRounds; ++round) {
         HS_SAT_T(const long long tr0_ = wall_clock64();)
         const bool wide = round >= boxRounds;
@@ -520,7 +737,7 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
                         st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
                         m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                     }
-                    ((ManS *)S.wsSC + (size_t)w * kMaxSCand)[kk] = m;
+                    ((ManS *)S.wsSC + (size_t)w * kAllSC)[kk] = m;
                     atomicOr(&R.scAcc[g], 1u << kk);
                     planeMan = true;
                 }
@@ -687,8 +904,8 @@ HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float
     else { me.lin = me.lin - p * me.invM; me.ang = me.ang - da; }
 }
 
-template <bool POS>
-HSD void phase_dd(const SimState &S, OctRes &R) {
+template <bool POS, bool SPILL>
+HSD void phase_dd(const SimState &S, OctRes &R, bool anySpill) {
     constexpr int GL = 8, PAIRS = GL / 2;
     const int L = threadIdx.x, g = L / GL, q = L % GL;
     const int h = q >> 1;                                         // this lane's pair within the world's 8 lanes
@@ -697,7 +914,7 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
     const int w = S.wbeg + g;                                     // the world's slot in the tiled columns
     const int ndd = R.ndd[g];
     const bool grab = R.hasGrab[g] != 0;
-    if (__ballot(R.ddAcc[g] != 0u || (POS && grab)) == 0ull) return;        // nothing to do in the whole octet
+    if (!(SPILL && anySpill) && __ballot(R.ddAcc[g] != 0u || (POS && grab)) == 0ull) return;        // nothing to do in the whole octet
     if (POS && grab && q == 0) {
         const int teams = S.teams[R.wid[g]];
         for (int a = 0; a < kMaxAgents; ++a) {
@@ -714,7 +931,7 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
             rbody_store_pose(R, g, kAgentSlot0 + a, A); rbody_store_pose(R, g, other, B);
         }
     }
-    ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kMaxDDCand;
+    ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kAllDD;
     const unsigned acc = R.ddAcc[g];
     const int nacc = __popc(acc);
     if (POS) {
@@ -808,6 +1025,8 @@ HSD void phase_dd(const SimState &S, OctRes &R) {
         }
     }
     wave_sync();
+    // (the world's SPILLED body-body pairs come after every pair above in pair order)
+    if (SPILL && __builtin_expect(anySpill, 0)) { spill_dd<POS>(spill_ctx(S), &R); wave_sync(); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -839,14 +1058,19 @@ HSD WallLists list_wall_bodies(OctRes &R, int nbodies, int lastRound) {
 HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
     if (meta_resp(meta) != RESP_DYNAMIC || b.np == 0) return;
     const int obj = meta_obj(meta);
-    BodyS me, none;
+    BodyS me;
     rbody_load(R, g, slot, me);
     const V3 gn = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
     const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
+    // agents are yaw-only bodies (obj_inv_inertia): their floor contacts share the manifold's normal multiplier
+    const bool yaw = slot >= kAgentSlot0;
+    float dj[4] = {0.f, 0.f, 0.f, 0.f}, share = 0.f;
+    if (yaw) share = yaw_ground_prepass(me, gn, b.np, hull_local_vertex(obj, b.vidx & 7), hull_local_vertex(obj, (b.vidx >> 3) & 7),
+                                        hull_local_vertex(obj, (b.vidx >> 6) & 7), hull_local_vertex(obj, (b.vidx >> 9) & 7), kGroundOff, dj);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (j < b.np) b.lam[j] += solve_point_position<false>(me, none, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7),
-                                                              V3{0.f, 0.f, 0.f}, b.off[j], gmuS);
+        if (j < b.np) b.lam[j] += solve_point_position_ground(me, gn, hull_local_vertex(obj, (b.vidx >> (3 * j)) & 7), kGroundOff, gmuS,
+                                                              yaw, dj[j], share);
     rbody_store_pose(R, g, slot, me);
 }
 HSD void ground_vel(OctRes &R, const BodyReg &b, int slot, int g, int meta) {
@@ -871,7 +1095,7 @@ HSD void wall_round(const SimState &S, OctRes &R, int first, int nwb) {
         const int sci = R.scInfo[slot][g];
         const int bsc = sci & 0xff, asc = sci >> 8;
         const unsigned acc = R.scAcc[g];
-        ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kMaxSCand;
+        ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kAllSC;
         BodyS me, none;
         rbody_load(R, g, slot, me);
         // the body's ACCEPTED candidates in candidate order, a lane at its own pace: a trip of the loop is a whole manifold
@@ -927,7 +1151,7 @@ HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int sl
     const int obj = meta_obj(meta);
     BodyS me, none;
     rbody_load(R, g, slot, me);
-    ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kMaxSCand;
+    ManS *const wsSC = (ManS *)S.wsSC + (size_t)(S.wbeg + g) * kAllSC;
 #pragma unroll 1
     while (todo != 0u) {
         const int k = bsc + __ffs((int)todo) - 1;
@@ -945,12 +1169,17 @@ HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int sl
             np = b.np;
         }
         body_refresh_inertia(me);
+        // the ground manifold of an agent (a yaw-only body): manifold-level normal part first (hs_solver.h)
+        const bool yaw = POS && !walls && slot >= kAgentSlot0;
+        float dj[4] = {0.f, 0.f, 0.f, 0.f}, share = 0.f;
+        if (yaw) share = yaw_ground_prepass(me, n, np, hull_local_vertex(obj, b.vidx & 7), hull_local_vertex(obj, (b.vidx >> 3) & 7),
+                                            hull_local_vertex(obj, (b.vidx >> 6) & 7), hull_local_vertex(obj, (b.vidx >> 9) & 7), kGroundOff, dj);
 #define HS_LAST_POINT(j)                                                                                                   \
         if ((j) < np) {                                                                                                    \
             const V3 rAj = walls ? ld3(m.rA[j]) : hull_local_vertex(obj, (b.vidx >> (3 * (j))) & 7);                       \
             const float lamj = walls ? m.lam[j] : b.lam[j];                                                                \
             if (POS) {                                                                                                     \
-                const float nl = lamj + solve_point_position<false>(me, none, n, rAj, V3{0.f, 0.f, 0.f}, walls ? m.offB[j] : b.off[j], mu); \
+                const float nl = lamj + solve_point_position_ground(me, n, rAj, walls ? m.offB[j] : kGroundOff, mu, yaw, dj[j], share); \
                 if (!walls) b.lam[j] = nl;                                                                                 \
                 else if (loc != kLocGlobal) man_lds_set_lam<ManS>(R.u.sat.clip, loc, (j), nl);                             \
                 else wsSC[k].lam[j] = nl;                                                                                  \
@@ -1170,6 +1399,56 @@ HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int 
     wave_sync();
 }
 
+// What follows the broadphase in a substep: convex tests -> body-body position solve -> static position passes ->
+// velocities from the pose change -> body-body and static velocity passes (-> integration for the next substep).
+#ifdef HS_PHASE_TIMING
+#define HS_TICK_PARAMS , long long &tk, long long (&acc)[10]
+#define HS_TICK_ARGS , tk, acc
+#define HS_TICK(i) { const long long now_ = wall_clock64(); acc[i] += now_ - tk; tk = now_; }
+#else
+#define HS_TICK_PARAMS
+#define HS_TICK_ARGS
+#define HS_TICK(i)
+#endif
+#define HS_BODY(r) const bool valid = (r) * 64 + L < nbodies; const int t_ = valid ? R.bodies[(r) * 64 + L] : 0; \
+                   const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
+template <int ROUNDS, bool SPILL>
+HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int NS, ItemCounts ic, bool integrateNext,
+                      const float *aforce HS_TICK_PARAMS) {
+    const int L = threadIdx.x;
+    const bool manGlobal = phase_sat<SPILL>(S, R, ic);
+    HS_TICK(3)
+    phase_dd<true, SPILL>(S, R, ic.anySpill);
+    HS_TICK(4)
+    // (with 6 agents a third round exists for up to 136 bodies, but an octet rarely holds more than 128: then round 1 is
+    // the last one that holds bodies, and the passes are two, not three)
+    const bool shortLast = ROUNDS == 3 && nbodies <= 128;
+    const int lastRound = shortLast ? 1 : ROUNDS - 1;
+    const WallLists wl = list_wall_bodies<ROUNDS>(R, nbodies, lastRound);
+    const int nLast = max(nbodies - 64 * lastRound, 0);            // bodies of the last round
+    const int nMerged = min(wl.nEarly, 64 - nLast);                 // listed bodies its idle lanes take
+    if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), true>(S, R, br, nbodies, nLast, nMerged);
+    else static_passes<ROUNDS, ROUNDS - 1, true>(S, R, br, nbodies, nLast, nMerged);
+    if (wl.nwb > nMerged) { wall_round<true>(S, R, nMerged, wl.nwb); wave_sync(); }
+    if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_static<true>(spill_ctx(S), &R, NS); wave_sync(); }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
+    if (manGlobal) mem_sync(); else wave_sync();   // (the multipliers of manifolds in the global workspace, for the velocity pass)
+    HS_TICK(5)
+    phase_dd<false, SPILL>(S, R, ic.anySpill);
+    HS_TICK(6)
+    if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), false>(S, R, br, nbodies, nLast, nMerged);
+    else static_passes<ROUNDS, ROUNDS - 1, false>(S, R, br, nbodies, nLast, nMerged);
+    if (wl.nwb > nMerged) { wall_round<false>(S, R, nMerged, wl.nwb); wave_sync(); }
+    if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_static<false>(spill_ctx(S), &R, NS); wave_sync(); }
+    if (integrateNext) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) integrate_body(R, br[r], slot, g, meta, aforce); }
+        wave_sync();
+    }
+    HS_TICK(7)
+}
+
 // ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
 // 6 agents (17 slots x 8 worlds = 136 bodies at most).
 template <int ROUNDS>
@@ -1178,10 +1457,8 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     S.wbeg = o * kTile;                               // first slot of the octet in the tiled columns
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
     const int noct = gridDim.x;
-    // The launch ends with its slowest wave, and under the dependency schedule k_observe's workgroups run on the same
-    // SIMDs beside the physics waves that are still at work: those keep the first claim on the issue slots.
-    // ... and among the physics waves the ones that were slow in the previous step (the same worlds: contact piles
-    // persist) go first on their SIMD: the launch ends with its slowest wave, and the partner of a slow wave has slack.
+    // The launch ends with its slowest wave: the physics waves that were slow in the previous step (the same worlds:
+    // contact piles persist) go first on their SIMD, the partner of a slow wave has slack.
     // Measured: k_physics 0.387 -> 0.380 ms; boosting a wave while it is inside a chain of manifolds or an extra round
     // of convex tests instead gave 0.382.
     const long long tStart = wall_clock64();
@@ -1196,18 +1473,9 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         else if (known) __builtin_amdgcn_s_setprio(0);
         else __builtin_amdgcn_s_setprio(2);
     }
-    if (S.stepPar >= 0 && L == 0) {                   // dependency schedule: clear the next step's half of the finish list
-        const int pn = S.stepPar ^ 1;
-        S.doneList[pn * noct + o] = -1;
-        if (o == 0) { S.doneTickets[pn] = 0; S.startedCount[pn] = 0; }
-        __hip_atomic_fetch_add(&S.startedCount[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 #ifdef HS_PHASE_TIMING
     // development aid: wall-clock ticks (100 MHz) per phase of every octet -> S.phaseTicks[octet][10]
     long long tk = wall_clock64(); long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define HS_TICK(i) { const long long now_ = wall_clock64(); acc[i] += now_ - tk; tk = now_; }
-#else
-#define HS_TICK(i)
 #endif
     // ---- the octet's columns -> LDS (the blocks are contiguous; worlds beyond N are zero padding = empty slots)
     copy_in(&R.pos[0][0][0], S.bpos, o); copy_in(&R.rot[0][0][0], S.brot, o);
@@ -1254,24 +1522,18 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     if (L < kTile) R.wallSeen[L] = 0u;                // from here on: this step's
     wave_sync();
     // A body keeps its (round, lane) for the whole step: which body it is comes from the list, its ground manifold
-    // and the agent's force stay in registers.
-#define HS_BODY(r) const bool valid = (r) * 64 + L < nbodies; const int t_ = valid ? R.bodies[(r) * 64 + L] : 0; \
-                   const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
+    // stays in registers.
     BodyReg br[ROUNDS];
+    const float *const aforce = S.aforce.octet(o);
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         BodyReg &b = br[r];
-        b.force = {0.f, 0.f, 0.f}; b.torque = 0.f; b.np = 0; b.vidx = 0;
+        b.np = 0; b.vidx = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { b.off[j] = 0.f; b.lam[j] = 0.f; }
+        for (int j = 0; j < 4; ++j) b.lam[j] = 0.f;
         HS_BODY(r)
-        if (valid && slot >= kAgentSlot0) {
-            const int a = slot - kAgentSlot0, w = S.wbeg + g;
-            b.force = {S.aforce(0 * kMaxAgents + a, w), S.aforce(1 * kMaxAgents + a, w), S.aforce(2 * kMaxAgents + a, w)};
-            b.torque = S.aforce(3 * kMaxAgents + a, w);
-        }
         // integrate for the first substep (the later ones happen at the end of the velocity pass)
-        if (valid) integrate_body(R, b, slot, g, meta);
+        if (valid) integrate_body(R, b, slot, g, meta, aforce);
     }
     wave_sync();
     HS_TICK(1)
@@ -1279,35 +1541,14 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect<ROUNDS>(S, R, NS);
         HS_TICK(2)
-        const bool manGlobal = phase_sat(S, R, ic);
-        HS_TICK(3)
-        phase_dd<true>(S, R);
-        HS_TICK(4)
-        // (with 6 agents a third round exists for up to 136 bodies, but an octet rarely holds more than 128: then round 1 is
-        // the last one that holds bodies, and the passes are two, not three)
-        const bool shortLast = ROUNDS == 3 && nbodies <= 128;
-        const int lastRound = shortLast ? 1 : ROUNDS - 1;
-        const WallLists wl = list_wall_bodies<ROUNDS>(R, nbodies, lastRound);
-        const int nLast = max(nbodies - 64 * lastRound, 0);            // bodies of the last round
-        const int nMerged = min(wl.nEarly, 64 - nLast);                 // listed bodies its idle lanes take
-        if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), true>(S, R, br, nbodies, nLast, nMerged);
-        else static_passes<ROUNDS, ROUNDS - 1, true>(S, R, br, nbodies, nLast, nMerged);
-        if (wl.nwb > nMerged) { wall_round<true>(S, R, nMerged, wl.nwb); wave_sync(); }
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
-        if (manGlobal) mem_sync(); else wave_sync();   // (the multipliers of manifolds in the global workspace, for the velocity pass)
-        HS_TICK(5)
-        phase_dd<false>(S, R);
-        HS_TICK(6)
-        if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), false>(S, R, br, nbodies, nLast, nMerged);
-        else static_passes<ROUNDS, ROUNDS - 1, false>(S, R, br, nbodies, nLast, nMerged);
-        if (wl.nwb > nMerged) { wall_round<false>(S, R, nMerged, wl.nwb); wave_sync(); }
-        if (sub + 1 < kNumSubsteps) {
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) integrate_body(R, br[r], slot, g, meta); }
-            wave_sync();
-        }
-        HS_TICK(7)
+        // (the instantiation with the spill path only for a substep in which a world of the octet has candidate pairs
+        // beyond the LDS capacities: a handful in millions of world-steps)
+#ifdef HS_SPILL_SINGLE
+        substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
+#else
+        if (__builtin_expect(ic.anySpill, 0)) substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
+        else substep_rest<ROUNDS, false>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
+#endif
     }
 #undef HS_BODY
     phase_post(S, R);
@@ -1329,20 +1570,6 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
             reset_world(S, myWorld, gen[L]);
         }
     }
-    // Publish the octet to k_observe, which runs beside this kernel and takes finished octets in the order of this
-    // list: the wave's stores have left it (vmcnt), one lane releases at agent scope (the XCDs' L2s are not coherent
-    // with each other) and appends the octet.
-    if (S.stepPar >= 0) {
-        mem_sync();
-        if (L == 0) {
-#ifndef HS_NO_RELEASE
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int ticket = __hip_atomic_fetch_add(&S.doneTickets[S.stepPar], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&S.doneList[S.stepPar * noct + ticket], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if (L == 0) {
         const int dt = (int)(wall_clock64() - tStart);
         S.octTicks[o] = dt;
@@ -1360,21 +1587,6 @@ __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     __shared__ union PhysLds { OctRes R; GenScratch gen[kTile]; } lds;
     static_assert(sizeof(PhysLds) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
     physics_step<ROUNDS>(S, lds.R, lds.gen);
-}
-
-// Holds the stream of k_observe back until every wave of k_physics has started, i.e. holds its slot on a CU: the
-// waiting k_observe workgroups that follow can then never keep a physics wave from being placed.  One wave.
-__global__ void __launch_bounds__(64) k_gate(SimState S, int noct, int doneFirst) {
-    if (threadIdx.x != 0) return;
-    // ... and, optionally, until `doneFirst` physics waves have finished: k_observe then fills the slots the finished
-    // waves leave in the tail of k_physics instead of competing with the waves that are still in the middle of it
-    bool started = false;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (!started) started = __hip_atomic_load(&S.startedCount[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= noct;
-        if (started && __hip_atomic_load(&S.doneTickets[S.stepPar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= doneFirst) return;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    S.status[2] = 2; *S.hostFlag = 1;      // (never observed; keeps a bug from hanging the GPU)
 }
 
 }  // namespace hs

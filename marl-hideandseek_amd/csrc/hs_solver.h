@@ -132,6 +132,78 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
     return lam;
 }
 
+// One contact point of a GROUND-PLANE manifold in the position pass (body against plane 0, no body B).  For an ordinary
+// body it is exactly solve_point_position<false>.  For a YAW-ONLY body (an agent: inverse inertia x, y = 0,
+// src/mgr.cpp:577-584) the normal part has been done for the whole manifold by yaw_ground_prepass (below): `dj` is
+// the point's penetration before any correction and `share` its equal share of the manifold's normal multiplier; what
+// remains per point is the static-friction correction, the same expressions for both kinds of body.
+HSD float solve_point_position_ground(BodyS &A, V3 n, V3 rAl, float offB, float muS, bool yaw, float dj, float share) {
+    BodyS none;
+    V3 rAw = qrot(A.rot, rAl);
+    V3 pA = A.pos + rAw;
+    const V3 pAprev = A.ppos + qrot(A.prot, rAl);
+    float lam;
+    if (!yaw) {
+        float d = dot(pA, n) - offB;
+        if (!(d > 0.f)) return 0.f;
+        const float dprev = dot(pAprev, n) - offB;
+        const float excess = dprev - kMaxDepenVel * kSubstepH;
+        if (excess > 0.f) d = d - excess;
+        if (!(d > 0.f)) return 0.f;
+        const float wsum = gen_inv_mass(A, rAw, n);
+        if (!(wsum > 0.f)) return 0.f;
+        lam = d / wsum;
+        apply_pos_impulse<false>(A, rAw, none, V3{0.f, 0.f, 0.f}, n * lam);
+        rAw = qrot(A.rot, rAl);
+        pA = A.pos + rAw;
+    } else {
+        if (!(dj > 0.f)) return 0.f;
+        lam = share;
+    }
+    const V3 dp = pA - pAprev;
+    const V3 dpt = dp - n * dot(dp, n);
+    const float lt2 = len2(dpt);
+    if (lt2 > 1e-12f) {
+        const float wts = gen_inv_mass_sq(A, rAw, dpt, lt2);
+        if (wts > 0.f) {
+            const float lim = (muS * lam) * wts;
+            if ((lt2 * lt2) * lt2 < lim * lim) apply_pos_impulse<false>(A, rAw, none, V3{0.f, 0.f, 0.f}, dpt * (lt2 / wts));
+        }
+    }
+    return lam;
+}
+// The manifold-level part for a yaw-only body (oracle: solve_ground_positions_yaw_only).  Such a body cannot tilt, so
+// its floor contacts cannot be resolved one after the other — the first would take the whole normal correction and
+// with it the whole friction budget of the substep, at a lever arm (a straight push spun the agent up).  The
+// penetrations of all points are evaluated before any correction, the body is lifted once by the deepest of them along
+// the normal (translation only), and the multiplier dmax / invM is shared equally by the touching points.  Returns the
+// share (0: nothing touches); r0..r3 are the contact points in the body frame.
+HSD float yaw_ground_prepass(BodyS &A, V3 n, int np, V3 r0, V3 r1, V3 r2, V3 r3, float off, float (&dj)[4]) {
+    int k = 0; float dmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dj[j] = 0.f;
+        if (j < np) {
+            const V3 r = j == 0 ? r0 : j == 1 ? r1 : j == 2 ? r2 : r3;
+            float d = dot(A.pos + qrot(A.rot, r), n) - off;
+            if (d > 0.f) {
+                const float excess = (dot(A.ppos + qrot(A.prot, r), n) - off) - kMaxDepenVel * kSubstepH;
+                if (excess > 0.f) d = d - excess;
+            }
+            dj[j] = d;
+            if (d > 0.f) { k++; dmax = fmaxf(dmax, d); }
+        }
+    }
+    if (k == 0 || !(A.invM > 0.f)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dj[j] = 0.f;
+        return 0.f;
+    }
+    const float lamT = dmax / A.invM;
+    A.pos = A.pos - (n * lamT) * A.invM;
+    return lamT / (float)k;
+}
+
 // One contact point of the velocity pass (dynamic friction, restitution 0).
 template <bool HAS_B>
 HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float lamN, float muD) {

@@ -84,17 +84,14 @@ struct SimState {
     int32_t *xCkptCtrl;    // [N]  CheckpointControl::trigger (sim.hpp:279-281)
     uint8_t *xCkpt;        // [N][sizeof(hs_checkpoint)]  (include/hideseek.h, sim.hpp:283-313)
     // --- contact-manifold workspace of the physics kernel (hs_k_physics.h): written by the lane that ran the convex
-    // test, read by the lanes that solve the contact; [N][kMaxDDCand] ManDD, [N][kMaxSCand] ManS (L2-resident)
+    // test, read by the lanes that solve the contact; one record for EVERY possible pair of a world, indexed by the pair's
+    // place in the world's candidate order: [slots][136] ManDD, [slots][646] ManS.  The fast path touches the first
+    // 16 / 24 places of a world at most (and usually none: its manifolds live in LDS); the rest is the spill path's.
     void *wsDD, *wsSC;
-    // --- dependency schedule between k_physics and k_observe (hideseek.hip launch_step): octets in the order their
-    // physics wave finished, double-buffered by step parity
-    int *doneList;         // [2][octets]  -1 = not finished yet
-    int *doneTickets;      // [2]
-    int *startedCount;     // [2] physics waves that have started (k_gate holds k_observe back until all have)
-    int stepPar;           // parity of this step, or -1: k_observe does not wait (init, checkpoints, sequential launches)
-    int *status;           // [4] device-side conditions: dropped body-body pairs, dropped body-static pairs, expired wait, -
+    unsigned short *spPair;   // [slots][136 + 646] pair codes of the candidates beyond the LDS capacities, at their places
+    int *spInfo;              // [slots][18] totals (body-body | body-static << 16), per body: first spilled static | count << 16
+    int *status;           // [4] sticky counters: body-body / body-static candidate pairs that took the spill path, -, -
                            // (include/hideseek.h hs_device_status); bumped only when something happens
-    int *hostFlag;         // pinned host word (device-visible): set to 1 together with any change of status
     long long *phaseTicks; // [octets][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
 };
 

@@ -288,16 +288,15 @@ class HideAndSeekSimulator:
         return bundle
 
     def device_status(self):
-        """hs_get_device_status: sticky device-side conditions (dropped broadphase pairs) and whether graphs are in use."""
+        """hs_get_device_status: sticky device-side counters — candidate pairs that took the spill path of the physics
+        kernel (beyond its LDS capacities; results unaffected), dropped pairs (always 0) — and whether graphs are in use."""
         st = _native.HsDeviceStatus()
         _check(self._L.hs_get_device_status(self._h, C.byref(st)))
         return {"dropped_dd_pairs": int(st.dropped_dd_pairs), "dropped_static_pairs": int(st.dropped_static_pairs),
                 "dropped_candidate_pairs": int(st.dropped_dd_pairs + st.dropped_static_pairs),
-                "graphs_in_use": bool(st.graphs_in_use), "sched_error": int(st.sched_error)}
-
-    def set_overlap(self, enabled):
-        """hs_set_overlap: the dependency schedule between k_physics and k_observe (default off, HS_OVERLAP=1); results are identical."""
-        _check(self._L.hs_set_overlap(self._h, int(bool(enabled))))
+                "spilled_dd_pairs": int(st.spilled_dd_pairs), "spilled_static_pairs": int(st.spilled_static_pairs),
+                "spilled_candidate_pairs": int(st.spilled_dd_pairs + st.spilled_static_pairs),
+                "graphs_in_use": bool(st.graphs_in_use)}
 
     def warning(self):
         """The library's last message for this thread (a warning after a successful call, e.g. dropped pairs)."""

@@ -27,7 +27,8 @@ class HsIfaceEntry(C.Structure):
 
 class HsDeviceStatus(C.Structure):
     _fields_ = [("dropped_dd_pairs", C.c_int64), ("dropped_static_pairs", C.c_int64),
-                ("graphs_in_use", C.c_int32), ("sched_error", C.c_int32)]
+                ("graphs_in_use", C.c_int32), ("reserved", C.c_int32),
+                ("spilled_dd_pairs", C.c_int64), ("spilled_static_pairs", C.c_int64)]
 
 
 # XLA custom-call targets (include/hideseek.h hs_xla_*): the key `sim.jax()` files each one under -> native symbol
@@ -60,7 +61,7 @@ def load():
     for n in ("hs_init", "hs_step", "hs_step_begin", "hs_step_end", "hs_save_checkpoints", "hs_load_checkpoints", "hs_render"):
         getattr(L, n).argtypes = [C.c_void_p]
         getattr(L, n).restype = C.c_int32
-    for n in ("hs_save_checkpoint", "hs_load_checkpoint", "hs_set_overlap", "hs_debug_inject_sched_error"):
+    for n in ("hs_save_checkpoint", "hs_load_checkpoint"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_int32]
         getattr(L, n).restype = C.c_int32
     for n in ("hs_jax_init", "hs_jax_step", "hs_jax_save_checkpoints", "hs_jax_load_checkpoints"):

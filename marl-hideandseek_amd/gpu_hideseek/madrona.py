@@ -51,12 +51,13 @@ _records = {}
 class Tensor:
     """Counterpart of madrona::py::Tensor (src/mgr.cpp:824-842): a NON-OWNING view of simulator memory.
 
-    Lifetime: the simulator owns the memory (src/mgr.hpp ownership convention).  A Tensor keeps its simulator
-    alive, but a torch / jax array made from it does not: do not use such arrays after the simulator has been
-    closed or deleted (`del sim`, scripts/benchmark.py:94)."""
+    Lifetime: the simulator owns the memory (src/mgr.hpp ownership convention) and neither a Tensor nor a torch / jax
+    array made from it keeps the simulator alive: `del sim` (scripts/benchmark.py:94) frees the HBM at once, as
+    `Manager::~Manager` does.  A Tensor knows its owner only weakly and refuses to hand out new views once the owner
+    is closed or gone (`to_torch`, `to_jax`, `__dlpack__` raise); arrays made EARLIER are the caller's to drop."""
 
     def __init__(self, owner, desc):
-        self._owner = owner            # keeps the simulator (and so the memory) alive
+        self._owner = owner            # weakref.proxy of the simulator: never extends its life
         self.ptr = desc.ptr
         self.dtype_id = desc.dtype
         self.shape = tuple(int(desc.dims[i]) for i in range(desc.ndim))
@@ -66,6 +67,14 @@ class Tensor:
     @property
     def dtype(self):
         return _DTYPES[self.dtype_id][2]
+
+    def _require_owner(self):
+        try:
+            if self._owner._h:
+                return
+        except ReferenceError:
+            pass
+        raise RuntimeError("the simulator that owns this tensor has been closed or deleted: its device memory is freed")
 
     def __dlpack_device__(self):
         return (_kDLROCM, self.gpu_id)
@@ -91,6 +100,7 @@ class Tensor:
         return rec[0]
 
     def __dlpack__(self, stream=None, **_):
+        self._require_owner()
         new_capsule = C.pythonapi.PyCapsule_New
         new_capsule.restype = C.py_object
         new_capsule.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -98,12 +108,14 @@ class Tensor:
 
     def to_torch(self):
         """Zero-copy torch view on cuda:gpu_id (madrona Tensor.to_torch, scripts/benchmark.py:38-39,47)."""
+        self._require_owner()
         if self._torch is None:
             import torch
             self._torch = torch.from_dlpack(self)
         return self._torch
 
     def to_jax(self):
+        self._require_owner()
         import jax.dlpack
         return jax.dlpack.from_dlpack(self)
 

@@ -21,11 +21,12 @@ namespace hsref {
 constexpr float kSubstepH = (1.f / 30.f) / 4.f;
 constexpr float kInvSubstepH = 120.f;
 constexpr float kGravityZ = -9.8f;            // sim.cpp:1360
-// Candidate-pair capacities per world per substep (pairs whose AABBs overlap; measured maxima on
-// the benchmark workload are 6 accepted body-body and 9 accepted body-wall manifolds).  Pairs
-// beyond the capacity are dropped in pair order, identically in the HIP kernels.
-constexpr int kMaxDDCand = 16;                 // body-body candidate pairs
-constexpr int kMaxSCand = 24;                 // body-(wall | plane>=1) candidate pairs
+// Candidate pairs per world per substep (pairs whose AABBs overlap) are bounded only by the body counts, as in the
+// reference (src/sim.cpp:1356-1361 sizes for every entity): 17 movable bodies give at most 136 body-body pairs, and a
+// body meets at most 36 walls + 2 extra planes.  No pair is ever dropped.  (The HIP kernels keep the first 16 / 24
+// candidates of a world in LDS and spill the rest to a global list — same pairs, same order, same results.)
+constexpr int kMaxDDCand = kNumDSlots * (kNumDSlots - 1) / 2;          // 136 body-body candidate pairs
+constexpr int kMaxSCand = kNumDSlots * (kMaxWalls + kMaxPlanes - 1);   // body-(wall | plane>=1) candidate pairs
 constexpr float kMaxDepenVel = 3.f;         // m/s, rate limit for pre-existing overlap
 
 // mgr.cpp:476-559 — inverse mass and friction per SimObject
@@ -475,6 +476,55 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
     }
 }
 
+// Ground-plane manifold of a YAW-ONLY body (an agent: inverse inertia x, y = 0, src/mgr.cpp:577-584).  Such a body cannot
+// tilt, so its (up to four) floor contacts cannot be resolved one after the other: the first would take the whole normal
+// correction — and with it the whole friction budget of the substep, at a lever arm, so that a straight push spun the agent
+// up (tests/test_oracle_first_principles.py::test_a_straight_push_does_not_spin_the_agent).  Instead the penetrations of
+// all points are evaluated BEFORE any correction; the body is lifted once, by the deepest of them, along the normal
+// (translation only: for a body that cannot tilt the plane's reaction passes through its centre); and the normal
+// multiplier lam = d / invM is shared equally by the touching points, each of which then gets its own static-friction
+// correction — at its own lever arm, limited by muS times its share — exactly as in solve_manifold_positions.  The
+// velocity pass is the ordinary one with the shared multipliers.
+static inline void solve_ground_positions_yaw_only(World &w, Manifold &m) {
+    DBody *A = &w.d[m.a];
+    BodyMass ma = body_mass(*A);
+    const BodyMass mb = {0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    const V3 n = m.n;
+    float dj[4]; V3 pAprev[4];
+    int k = 0; float dmax = 0.f;
+    for (int j = 0; j < m.np; ++j) {
+        V3 pA = A->pos + qrot(A->rot, m.rA[j]);
+        float d = dot(pA, n) - m.offB[j];
+        pAprev[j] = A->prevPos + qrot(A->prevRot, m.rA[j]);
+        if (d > 0.f) {
+            float excess = (dot(pAprev[j], n) - m.offB[j]) - kMaxDepenVel * kSubstepH;
+            if (excess > 0.f) d = d - excess;
+        }
+        dj[j] = d;
+        if (d > 0.f) { k++; dmax = fmaxf(dmax, d); }
+    }
+    if (k == 0 || !(ma.invM > 0.f)) return;
+    const float lamT = dmax / ma.invM;
+    A->pos = A->pos - (n * lamT) * ma.invM;
+    const float share = lamT / (float)k;
+    for (int j = 0; j < m.np; ++j) {
+        if (!(dj[j] > 0.f)) continue;
+        m.lambdaN[j] += share;
+        V3 rAw = qrot(A->rot, m.rA[j]);
+        V3 dp = (A->pos + rAw) - pAprev[j];
+        V3 dpt = dp - n * dot(dp, n);
+        float lt2 = len2(dpt);
+        if (lt2 > 1e-12f) {
+            float wts = gen_inv_mass_sq(ma, rAw, dpt, lt2);
+            if (wts > 0.f) {
+                float lim = (m.muS * share) * wts;
+                if ((lt2 * lt2) * lt2 < lim * lim) apply_pos_impulse(A, ma, rAw, nullptr, mb, V3{0.f, 0.f, 0.f}, dpt * (lt2 / wts));
+            }
+        }
+    }
+}
+static inline bool yaw_only(int32_t obj) { V3 i = obj_inv_inertia(obj); return i.x == 0.f && i.y == 0.f && i.z != 0.f; }
+
 static inline void apply_vel_impulse(DBody *A, const BodyMass &ma, V3 rA, DBody *B, const BodyMass &mb,
                                      V3 rB, V3 p) {   // A gets +p, B gets -p
     A->lin = A->lin + p * ma.invM;
@@ -619,7 +669,7 @@ static inline void physics_substep(World &w) {
             if (w.d[j].objType == OBJ_NONE) continue;
             if (w.d[i].response != RESP_DYNAMIC && w.d[j].response != RESP_DYNAMIC) continue;
             if (!hull_aabb_overlap(hulls[i], hulls[j])) continue;
-            if (ndd < kMaxDDCand) { ddA[ndd] = i; ddB[ndd] = j; ndd++; }
+            ddA[ndd] = i; ddB[ndd] = j; ndd++;
         }
     }
     // static candidates per movable body: planes 1.. (always), then walls whose AABB overlaps;
@@ -628,14 +678,14 @@ static inline void physics_substep(World &w) {
     for (int i = 0; i < kNumDSlots; ++i) {
         if (w.d[i].objType == OBJ_NONE || w.d[i].response != RESP_DYNAMIC) continue;
         for (int p = 1; p < w.numPlanes; ++p)
-            if (nsc < kMaxSCand) { scBody[nsc] = i; scStatic[nsc] = kMaxWalls + p; nsc++; }
+            { scBody[nsc] = i; scStatic[nsc] = kMaxWalls + p; nsc++; }
         const Hull &hb = hulls[i];
         for (int k = 0; k < w.numWalls; ++k) {
             const WallS &ws = w.walls[k];
             if (!(hb.lo.x <= ws.cx + ws.hx && ws.cx - ws.hx <= hb.hi.x &&
                   hb.lo.y <= ws.cy + ws.hy && ws.cy - ws.hy <= hb.hi.y && hb.lo.z <= 2.5f && 0.f <= hb.hi.z))
                 continue;
-            if (nsc < kMaxSCand) { scBody[nsc] = i; scStatic[nsc] = k; nsc++; }
+            scBody[nsc] = i; scStatic[nsc] = k; nsc++;
         }
     }
 
@@ -669,7 +719,10 @@ static inline void physics_substep(World &w) {
     for (int a = 0; a < kMaxAgents; ++a) if (w.agentActive[a]) solve_grab_joint(w, a);
     for (int k = 0; k < ndd; ++k) if (dd[k].np > 0) solve_manifold_positions(w, dd[k]);
     for (int i = 0; i < kNumDSlots; ++i) {
-        if (ground[i].np > 0) solve_manifold_positions(w, ground[i]);
+        if (ground[i].np > 0) {
+            if (yaw_only(w.d[i].objType)) solve_ground_positions_yaw_only(w, ground[i]);
+            else solve_manifold_positions(w, ground[i]);
+        }
         for (int k = 0; k < nsc; ++k) if (scBody[k] == i && sc[k].np > 0) solve_manifold_positions(w, sc[k]);
     }
 

@@ -180,8 +180,12 @@ def test_cube_on_the_locked_ramp_slips_because_tan_theta_exceeds_mu_s(oracle):
 
 def test_floor_friction_holds_a_resting_agent_and_yields_to_a_large_force(oracle):
     """Agent on the floor: mu_s = (0.5 + 2) / 2 = 1.25, m = 1 (src/mgr.cpp:476-559) -> Coulomb threshold 12.25 N.
-    No force: stays exactly where it is.  36 N forward (action 8 -> 12 * 3 N, src/sim.cpp:221-223): accelerates
-    forward, slower than the frictionless 36 m/s^2."""
+    No force: stays exactly where it is.  36 N forward (action 8 -> 12 * 3 N, src/sim.cpp:221-223) exceeds the static
+    threshold, so it moves forward — far slower than the frictionless 36 m/s^2: the table's KINETIC coefficient for an
+    agent on the floor is (16 + 2) / 2 = 9, i.e. 88 N of sliding friction against a 36 N push, so once it slips it is braked
+    again within the substep (stick-slip creep, as for the cube on the ramp below): the displacement grows step by step
+    and the velocity left at the end of a step is small but forward.  And it creeps STRAIGHT: no sideways drift beyond a
+    fraction of the forward motion (with the whole floor reaction on one corner it used to veer off and spin)."""
     for a, moves in ((5, False), (8, True)):
         ref = make(oracle)
         x, y = free_spot(ref)
@@ -194,12 +198,10 @@ def test_floor_friction_holds_a_resting_agent_and_yields_to_a_large_force(oracle
         if not moves:
             assert np.array_equal(d, np.zeros(3, np.float32)) and not b[0, 11, 7:13].any()
         else:
-            assert 0.002 < d[1] < 0.5 * 36 * 0.1 ** 2 and b[0, 11, 8] > 0.1, d
+            assert 0.002 < d[1] < 0.5 * 36 * 0.1 ** 2 and b[0, 11, 8] > 0.02, d
+            assert abs(d[0]) < 0.25 * d[1] and abs(b[0, 11, 12]) < 0.1, (d, b[0, 11, 12])
 
 
-@pytest.mark.xfail(reason="known deviation: a yaw-only body (agent) takes the whole floor reaction at the first of its four "
-                          "contact points, so the friction of a straight push has a lever arm and spins it up "
-                          "(~0.3 rad/s per step at 24 N); DESIGN.md 'Known deviations'", strict=True)
 def test_a_straight_push_does_not_spin_the_agent(oracle):
     ref = make(oracle)
     x, y = free_spot(ref)

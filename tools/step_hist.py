@@ -5,7 +5,7 @@ import gpu_hideseek
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
 sim = gpu_hideseek.HideAndSeekSimulator(exec_mode=1, gpu_id=0, num_worlds=N, sim_flags=0, rand_seed=0, min_hiders=2, max_hiders=2,
                                         min_seekers=2, max_seekers=2, num_pbt_policies=1)
-sim.init(); sim.set_overlap(False); sim.set_profiling(True)
+sim.init(); sim.set_profiling(True)
 act = sim.action_tensor().to_torch()
 ph, ob = [], []
 for i in range(485):

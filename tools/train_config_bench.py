@@ -47,7 +47,9 @@ for _ in range(STEPS):
 strm.synchronize()
 dt = time.perf_counter() - t0
 st = sim.device_status()
+assert st["dropped_candidate_pairs"] == 0, st          # pairs beyond the LDS capacities spill (counted), none is dropped
 print(json.dumps({"config": "BASELINE configs[4] simulator side: %d worlds, 3+3 agents, flags 13, seed 5, random policy, stream_step with caller buffers" % N,
                   "steps": STEPS, "ms_per_step": dt / STEPS * 1e3, "world_steps_per_s": N * STEPS / dt,
                   "agent_steps_per_s": N * A * STEPS / dt, "dropped_candidate_pairs": st["dropped_candidate_pairs"],
+                  "spilled_candidate_pairs": st["spilled_candidate_pairs"],
                   "finite": bool(all(torch.isfinite(o).all() for o in obs if o.dtype == torch.float32))}))
