@@ -1063,7 +1063,11 @@ HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
     const V3 gn = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
     const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
     // agents are yaw-only bodies (obj_inv_inertia): their floor contacts share the manifold's normal multiplier
+#ifdef HS_EXP_NO_YAW
+    const bool yaw = false;
+#else
     const bool yaw = slot >= kAgentSlot0;
+#endif
     float dj[4] = {0.f, 0.f, 0.f, 0.f}, share = 0.f;
     if (yaw) share = yaw_ground_prepass(me, gn, b.np, hull_local_vertex(obj, b.vidx & 7), hull_local_vertex(obj, (b.vidx >> 3) & 7),
                                         hull_local_vertex(obj, (b.vidx >> 6) & 7), hull_local_vertex(obj, (b.vidx >> 9) & 7), kGroundOff, dj);
@@ -1170,7 +1174,11 @@ HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int sl
         }
         body_refresh_inertia(me);
         // the ground manifold of an agent (a yaw-only body): manifold-level normal part first (hs_solver.h)
+#ifdef HS_EXP_NO_YAW
+        const bool yaw = false;
+#else
         const bool yaw = POS && !walls && slot >= kAgentSlot0;
+#endif
         float dj[4] = {0.f, 0.f, 0.f, 0.f}, share = 0.f;
         if (yaw) share = yaw_ground_prepass(me, n, np, hull_local_vertex(obj, b.vidx & 7), hull_local_vertex(obj, (b.vidx >> 3) & 7),
                                             hull_local_vertex(obj, (b.vidx >> 6) & 7), hull_local_vertex(obj, (b.vidx >> 9) & 7), kGroundOff, dj);
@@ -1543,7 +1551,9 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         HS_TICK(2)
         // (the instantiation with the spill path only for a substep in which a world of the octet has candidate pairs
         // beyond the LDS capacities: a handful in millions of world-steps)
-#ifdef HS_SPILL_SINGLE
+#ifdef HS_EXP_NO_SPILL
+        substep_rest<ROUNDS, false>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
+#elif defined(HS_SPILL_SINGLE)
         substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
 #else
         if (__builtin_expect(ic.anySpill, 0)) substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);

