@@ -274,6 +274,14 @@ int32_t hs_debug_observe_ticks(hs_sim *sim, int64_t out[16]);
  * items, rounds of 32 pairs, colliding pairs, contact-generation rounds. */
 int32_t hs_debug_sat_counters(hs_sim *sim, int64_t out[16]);
 
+/* The DEVICE's hull tables for one SimObject (src/sim.hpp:78-88; 3 = wall, unit size), evaluated by a one-lane kernel through
+ * the very functions the convex tests use (csrc/hs_collide.h: packed topology, closed-form vertices) at the identity
+ * pose: verts [8][3], faces [6][4] (-1 padded), counts {nv, nf, ne, ned}, normals [6][3], edges [12][3] = v0 v1 dir,
+ * local [8][3] = hull_local_vertex (the contact points of plane manifolds).  tests/test_gpu_hulls.py pins them to
+ * tests/golden/hulls.npz, i.e. to data/{cube,wall,agent,ramp,elongated}_collision.obj of the reference. */
+int32_t hs_debug_dump_hull(int32_t obj, float *verts, int32_t *faces, int32_t *counts, float *normals, int32_t *edges,
+                           float *local);
+
 /* Profiling aid: one dword-per-lane coalesced copy of `bytes` bytes (read + write), used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */
 int32_t hs_debug_calibrate(int64_t bytes);

@@ -734,6 +734,44 @@ int32_t hs_debug_calibrate(int64_t bytes) {
     return HS_OK;
 }
 
+// hs_debug_dump_hull: the hull tables as the kernels see them (hs_collide.h), one lane.
+__global__ void k_dump_hull(int obj, float *verts, int *faces, int *counts, float *normals, int *edges, float *local) {
+    using namespace hs;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const HullRef h = obj == OBJ_WALL ? hull_ref_wall(0.f, 0.f, 1.f, 1.f) : hull_ref_body(obj, V3{0.f, 0.f, 0.f}, Q{1.f, 0.f, 0.f, 0.f});
+    const int nv = hull_nv(h), nf = hull_nf(h), ne = hull_ne(h);
+    counts[0] = nv; counts[1] = nf; counts[2] = ne; counts[3] = hull_ned(h);
+    for (int i = 0; i < nv; ++i) {
+        const V3 v = hull_v(h, i);
+        verts[i * 3] = v.x; verts[i * 3 + 1] = v.y; verts[i * 3 + 2] = v.z;
+        const V3 l = obj == OBJ_WALL ? V3{0.f, 0.f, 0.f} : hull_local_vertex(obj, i);
+        local[i * 3] = l.x; local[i * 3 + 1] = l.y; local[i * 3 + 2] = l.z;
+    }
+    for (int f = 0; f < nf; ++f) {
+        for (int k = 0; k < 4; ++k) faces[f * 4 + k] = k < hull_fcnt(h, f) ? hull_fidx(h, f, k) : -1;
+        const V3 n = hull_fn(h, f);
+        normals[f * 3] = n.x; normals[f * 3 + 1] = n.y; normals[f * 3 + 2] = n.z;
+    }
+    for (int e = 0; e < ne; ++e) { int v0, v1, d; hull_edge(h, e, &v0, &v1, &d); edges[e * 3] = v0; edges[e * 3 + 1] = v1; edges[e * 3 + 2] = d; }
+}
+int32_t hs_debug_dump_hull(int32_t obj, float *verts, int32_t *faces, int32_t *counts, float *normals, int32_t *edges, float *local) {
+    if (!verts || !faces || !counts || !normals || !edges || !local) return fail(HS_ERR_INVALID_ARG, "null argument");
+    if (obj != hs::OBJ_CUBE && obj != hs::OBJ_WALL && obj != hs::OBJ_HIDER && obj != hs::OBJ_SEEKER && obj != hs::OBJ_RAMP && obj != hs::OBJ_BOX)
+        return fail(HS_ERR_INVALID_ARG, "no collision hull for this SimObject");
+    char *d = nullptr;
+    const size_t nb = (24 + 24 + 8 + 18 + 36 + 24) * 4;
+    HS_HIP(hipMalloc((void **)&d, nb));
+    HS_HIP(hipMemset(d, 0, nb));
+    float *dv = (float *)d; int *df = (int *)(dv + 24), *dc = df + 24; float *dn = (float *)(dc + 8); int *de = (int *)(dn + 18); float *dl = (float *)(de + 36);
+    hipLaunchKernelGGL(k_dump_hull, dim3(1), dim3(64), 0, nullptr, (int)obj, dv, df, dc, dn, de, dl);
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(verts, dv, 24 * 4, hipMemcpyDeviceToHost)); HS_HIP(hipMemcpy(faces, df, 24 * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(counts, dc, 4 * 4, hipMemcpyDeviceToHost)); HS_HIP(hipMemcpy(normals, dn, 18 * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(edges, de, 36 * 4, hipMemcpyDeviceToHost)); HS_HIP(hipMemcpy(local, dl, 24 * 4, hipMemcpyDeviceToHost));
+    HS_HIP(hipFree(d));
+    return HS_OK;
+}
+
 // DLPack deleter for the non-owning tensor views handed to Python: the simulator owns the memory, the
 // binding keeps the DLManagedTensor records alive, so there is nothing to free (and nothing here may call
 // back into an interpreter that is shutting down).

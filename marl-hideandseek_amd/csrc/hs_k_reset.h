@@ -444,7 +444,10 @@ HSD void regenerate_world(const SimState &S, int w, int level, const hs_checkpoi
 
 // Keeps SimState::slotHdr in step with the per-world scalars it mirrors.
 HSD void write_slot_hdr(const SimState &S, int w, int ps) {
-    S.slotHdr[ps] = make_int4(w, S.numWalls[w] | (S.numPlanes[w] << 8) | (S.curEpisodeStep[w] << 16), S.counts[w], S.teams[w]);
+    // (the step counter is unbounded under IgnoreEpisodeLength, sim.cpp:196; k_observe only asks "step <= 96" and
+    // "96 - step", so the header carries it saturated at 0x7fff instead of letting it overflow the 16 bits)
+    const int step = S.curEpisodeStep[w];
+    S.slotHdr[ps] = make_int4(w, S.numWalls[w] | (S.numPlanes[w] << 8) | ((step < 0x7fff ? step : 0x7fff) << 16), S.counts[w], S.teams[w]);
 }
 
 // resetSystem (src/sim.cpp:172-200) for one world

@@ -67,8 +67,21 @@ def lib():
         L.hsref_collide.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.hsref_collide.restype = C.c_int32
+        L.hsref_hull_tables.argtypes = [C.c_int32] + [C.c_void_p] * 6
+        L.hsref_hull_tables.restype = None
         _lib = L
     return _lib
+
+
+def hull_tables(obj):
+    """The oracle's hull of SimObject `obj` (identity pose; unit wall): dict of verts [nv,3], faces (list of index
+    loops), normals [nf,3], edges [ne,3] = v0 v1 direction id, aabb (lo, hi)."""
+    v = np.zeros((8, 3), np.float32); f = np.full((6, 4), -1, np.int32); c = np.zeros(4, np.int32)
+    n = np.zeros((6, 3), np.float32); e = np.zeros((12, 3), np.int32); a = np.zeros(6, np.float32)
+    lib().hsref_hull_tables(int(obj), v.ctypes.data, f.ctypes.data, c.ctypes.data, n.ctypes.data, e.ctypes.data, a.ctypes.data)
+    nv, nf, ne, _ = c
+    return {"verts": v[:nv], "faces": [[int(i) for i in row if i >= 0] for row in f[:nf]], "normals": n[:nf],
+            "edges": e[:ne], "aabb": (a[:3].copy(), a[3:].copy())}
 
 
 # name -> (export id, dtype, trailing shape, per-agent?)   (mgr.cpp:1062-1331)

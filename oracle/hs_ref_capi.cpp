@@ -131,4 +131,23 @@ int32_t hsref_collide(int32_t objA, const float *posA, const float *rotA, int32_
     return m.np;
 }
 
+// The oracle's own hull tables for one SimObject, as its collision code sees them (identity pose; a unit wall for
+// OBJ_WALL), plus the object-space AABB the level generator uses: tests/test_oracle_hulls.py pins them to
+// tests/golden/hulls.npz, i.e. to data/*_collision.obj of the reference.
+// verts [8][3], faces [6][4] (-1 padded), counts {nv, nf, ne, ned}, normals [6][3], edges [12][3] = v0 v1 dir, aabb [6]
+void hsref_hull_tables(int32_t obj, float *verts, int32_t *faces, int32_t *counts, float *normals, int32_t *edges, float *aabb) {
+    Hull h;
+    if (obj == OBJ_WALL) { WallS w = {0.f, 0.f, 1.f, 1.f}; hull_from_wall(h, w); }
+    else hull_from_body(h, obj, {0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f});
+    counts[0] = h.nv; counts[1] = h.nf; counts[2] = h.ne; counts[3] = h.ned;
+    for (int i = 0; i < h.nv; ++i) { verts[i * 3] = h.v[i].x; verts[i * 3 + 1] = h.v[i].y; verts[i * 3 + 2] = h.v[i].z; }
+    for (int f = 0; f < h.nf; ++f) {
+        for (int k = 0; k < 4; ++k) faces[f * 4 + k] = k < h.fcnt[f] ? h.fidx[f][k] : -1;
+        normals[f * 3] = h.fn[f].x; normals[f * 3 + 1] = h.fn[f].y; normals[f * 3 + 2] = h.fn[f].z;
+    }
+    for (int e = 0; e < h.ne; ++e) { edges[e * 3] = h.e0[e]; edges[e * 3 + 1] = h.e1[e]; edges[e * 3 + 2] = h.edir[e]; }
+    AABB a = object_aabb(obj);
+    aabb[0] = a.lo.x; aabb[1] = a.lo.y; aabb[2] = a.lo.z; aabb[3] = a.hi.x; aabb[4] = a.hi.y; aabb[5] = a.hi.z;
+}
+
 }  // extern "C"

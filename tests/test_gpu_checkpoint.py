@@ -268,3 +268,29 @@ def test_replay_log_round_trip(oracle, tmp_path):
         assert torch.equal(player.self_data_tensor().to_torch().view(torch.int32), self_data.view(torch.int32)), t
         assert torch.equal(player.lidar_tensor().to_torch().view(torch.int32), lidar.view(torch.int32)), t
         assert torch.equal(player.global_positions_tensor().to_torch().view(torch.int32), gpos.view(torch.int32)), t
+
+
+def test_unbounded_episode_step_does_not_corrupt_the_prep_counter(oracle):
+    """under IgnoreEpisodeLength the step counter grows without bound (src/sim.cpp:196).  k_observe reads it from
+    a 16-bit field of the slot header; a step of 40 000 (planted through a checkpoint) must leave prep_counter alone, as
+    the reference does after step 96 (src/sim.cpp:461-463), instead of wrapping into the preparation phase again."""
+    import torch
+    n = 16
+    sim, ref, gt = make_pair(oracle, n, flags=2, seed=4)
+    ctrl, ck = _ckpt_views(sim)
+    drive(sim, ref, gt, 3, "bench", check_every=3)
+    ctrl.view(torch.int32)[:] = 1
+    ref.tensor("ckpt_ctrl")[:] = 1
+    sim.save_checkpoints(); ref.save_checkpoints()
+    for step in (32767, 40000, 70000):
+        rec = ck.view(torch.int32).view(n, 348)
+        rec[:, 4] = step                                             # Checkpoint::episodeStep
+        ref.tensor("ckpt").view(np.int32).reshape(n, 348)[:, 4] = step
+        ctrl.view(torch.int32)[:] = 1
+        ref.tensor("ckpt_ctrl")[:] = 1
+        sim.load_checkpoints(); ref.load_checkpoints()
+        ctrl.zero_(); ref.tensor("ckpt_ctrl")[:] = 0
+        assert_equal_state(sim, ref, gt, f"loaded at step {step}")
+        drive(sim, ref, gt, 2, "bench", check_every=1)
+        _, info = sim.debug_walls()
+        assert (info[:, 6] == step + 2).all()

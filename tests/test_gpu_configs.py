@@ -8,11 +8,19 @@ ZeroAgentVelocity, seed 5, 3 hiders + 3 seekers, actions from the real bucket ra
 (Manager::gpuJAXStep, src/mgr.cpp:379-398, 1006-1022).
 
 Full-size runs are checked through size-independent properties (finite state, the done / prep-counter /
-reward timeline, seed rows = {episode, GLOBAL world id}); sampled world ranges — one straddling a 64-world
-workgroup boundary near the tail, one holding the very last worlds — are compared with the oracle bit for bit.
+reward timeline, seed rows = {episode, GLOBAL world id}) AND against the oracle on EVERY world, bit for bit: the oracle
+steps the whole batch beside the GPU on all host threads (no sampled ranges).  configs[1] — the
+benchmark batch, 16 000 worlds x 245 steps across the lock-step regeneration — is here as well.
 """
+import os
+
 import numpy as np
 import pytest
+
+
+def _threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 32))
 
 pytestmark = pytest.mark.gpu
 
@@ -40,11 +48,11 @@ def test_config3_last_shard_of_131072_worlds(oracle):
         min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1, world_offset=OFF)
     sim.init()
     act = sim.action_tensor().to_torch()
-    # sampled local world ranges: interior, straddling the workgroup boundary at 16320, and the last worlds
-    ranges = [(4999, 64), (16300, 64), (N - 20, 20)]
+    # the oracle runs the WHOLE shard beside the GPU (every world, not sampled ranges)
+    ranges = [(0, N)]
     refs = []
     for lo, n in ranges:
-        r = oracle.RefSim(n, rand_seed=0, world_offset=OFF + lo, threads=8)
+        r = oracle.RefSim(n, rand_seed=0, world_offset=OFF + lo, threads=_threads())
         r.init()
         refs.append(r)
     gdev = torch.arange(OFF * A, (OFF + N) * A, device=act.device, dtype=torch.int64)
@@ -60,6 +68,13 @@ def test_config3_last_shard_of_131072_worlds(oracle):
             r.tensor("action")[:, 1] = _hash(np, g, s, 1, 10) - 5
             r.step()
         sim.step()
+        if s % 7 == 6:                 # every 7th step: body state and the observations that feed a policy, every world
+            gb, gm = sim.debug_bodies()
+            rb, rm = refs[0].bodies()
+            assert np.array_equal(gm, rm) and np.array_equal(bits(gb), bits(rb)), s
+            for k in ("self_data", "lidar", "box_data", "reward"):
+                got = getattr(sim, k + "_tensor")().to_torch().cpu().numpy().reshape(refs[0].tensor(k).shape)
+                assert np.array_equal(bits(got), bits(refs[0].tensor(k))), (s, k)
         # timeline (sim.cpp:806-841, 448-464): every world is in lock-step
         if s in (0, 50, 94, 95, 200, 238, 239, 240, 244):
             ep_step = s % 240          # curEpisodeStep the step ran with
@@ -110,11 +125,11 @@ def test_config4_jax_train_workload_through_stream_step(oracle):
     pol = torch.zeros(R, 1, dtype=torch.int32, device=dev)
     strm = torch.cuda.Stream()
     sim.stream_init(strm.cuda_stream, obs)
-    ranges = [(7000, 48), (N - 40, 40)]          # the second one crosses the last workgroup boundary (15 936 + 64)
+    ranges = [(0, N)]                            # the oracle runs every world beside the GPU
     refs = []
     for lo, n in ranges:
         r = oracle.RefSim(n, sim_flags=FLAGS, rand_seed=SEED, min_hiders=3, max_hiders=3, min_seekers=3,
-                          max_seekers=3, world_offset=lo, threads=8)
+                          max_seekers=3, world_offset=lo, threads=_threads())
         r.init()
         refs.append(r)
     gdev = torch.arange(R, device=dev, dtype=torch.int64)
@@ -157,3 +172,43 @@ def test_config4_jax_train_workload_through_stream_step(oracle):
         rb, rm = r.bodies()
         assert np.array_equal(bits(body[lo:lo + n]), bits(rb)) and np.array_equal(meta[lo:lo + n], rm), lo
     assert sim.device_status()["dropped_candidate_pairs"] == 0
+
+
+def test_config1_benchmark_batch_every_world_against_the_oracle(oracle):
+    """BASELINE.json configs[1]: 16 000 worlds, 2 hiders + 2 seekers, flags 0, seed 0, move actions in [-5, 4] on columns
+    0-1 (scripts/benchmark.py:21-35, 82-84), 245 steps — across the regeneration of every level at step 240.  Every exported
+    tensor, body and wall of every world against the oracle at every 7th step and at the end."""
+    import torch
+    import gpu_hideseek
+    N, A, STEPS = 16000, 4, 245
+    sim = gpu_hideseek.HideAndSeekSimulator(
+        exec_mode=gpu_hideseek.madrona.ExecMode.CUDA, gpu_id=0, num_worlds=N, sim_flags=0, rand_seed=0,
+        min_hiders=2, max_hiders=2, min_seekers=2, max_seekers=2, num_pbt_policies=1)
+    ref = oracle.RefSim(N, rand_seed=0, threads=_threads())
+    sim.init(); ref.init()
+    act = sim.action_tensor().to_torch()
+    gdev = torch.arange(N * A, device=act.device, dtype=torch.int64)
+    gnp = np.arange(N * A, dtype=np.int64)
+    names = OBS + ["reward", "done", "global_positions", "episode_result", "seed", "action"]
+    checked = 0
+    for s in range(STEPS):
+        for c in (0, 1):
+            act[:, c] = (_hash(torch, gdev, s, c, 10) - 5).to(torch.int32)
+            ref.tensor("action")[:, c] = _hash(np, gnp, s, c, 10) - 5
+        sim.step(); ref.step()
+        if s % 7 == 6 or s == STEPS - 1:
+            gb, gm = sim.debug_bodies()
+            rb, rm = ref.bodies()
+            assert np.array_equal(gm, rm), s
+            bad = np.argwhere(bits(gb) != bits(rb))
+            assert bad.size == 0, (s, bad[:4].tolist())
+            gw, gi = sim.debug_walls()
+            rw, ri = ref.walls()
+            assert np.array_equal(gi, ri) and np.array_equal(bits(gw), bits(rw)), s
+            for k in names:
+                got = getattr(sim, k + "_tensor")().to_torch().cpu().numpy().reshape(ref.tensor(k).shape)
+                assert np.array_equal(bits(got), bits(ref.tensor(k))), (s, k)
+            checked += 1
+    assert checked == 36
+    st = sim.device_status()
+    assert st["dropped_candidate_pairs"] == 0

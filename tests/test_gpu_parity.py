@@ -173,7 +173,8 @@ def test_golden_level_layouts():
 def test_full_size_properties_and_shard_equivalence(oracle):
     """BASELINE.json configs[1] size (16 000 worlds): size-independent properties — determinism, shard
     equivalence (worlds [k*N/4,(k+1)*N/4) of a sharded run equal the monolithic run bit for bit, SURVEY
-    §8c-4), finite state, the done/prep timeline — plus oracle parity on a sampled sub-range."""
+    §8c-4), finite state, the done/prep timeline — plus oracle parity on a sub-range (every world of this batch is
+    compared with the oracle over 245 steps in tests/test_gpu_configs.py)."""
     import torch
     import gpu_hideseek
     N, A, steps = 16000, 4, 12
