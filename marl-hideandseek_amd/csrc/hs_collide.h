@@ -285,7 +285,8 @@ HSD void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3 *c1, V3 *c2) {
 // LDS scratch for polygon clipping: two ping-pong polygons of up to 8 vertices per lane, laid out
 // [buffer][vertex][component][lane] so that the lanes of a wave hit different banks (a
 // per-lane struct of 48 words would be a 16-way bank conflict on every access).
-constexpr int kClipLanes = 32;          // lanes of a wave that run the convex test (phase_sat)
+constexpr int kSatPairs = 32;           // pairs per round of the separating-axis search (two lanes per pair)
+constexpr int kClipLanes = 48;          // lanes of a wave that generate contacts in one round (each owns a column of the scratch)
 constexpr int kClipWords = 2 * 8 * 3 * kClipLanes;
 struct ClipBuf { float *base; int lane; };
 HSD V3 cb_get(const ClipBuf &b, int w, int i) {

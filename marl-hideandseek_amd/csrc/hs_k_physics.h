@@ -29,6 +29,11 @@
 #include "hs_solver.h"
 #include "hs_k_reset.h"
 
+// weight of a body-body candidate pair against a body-static one in the load estimate k_balance sorts the worlds by
+#ifndef HS_LOAD_DD_WEIGHT
+#define HS_LOAD_DD_WEIGHT 1
+#endif
+
 namespace hs {
 
 constexpr int kPhysThreads = 64;                   // one wave
@@ -53,13 +58,12 @@ constexpr int kSpInfoWords = kNumDSlots + 1;      // S.spInfo per world: totals 
 // ---- the octet's resident working set (LDS) ----
 // Every column is [row][world of the octet] exactly like its block in HBM (hs_state.h Col), so loading and storing
 // are linear copies, and a wave whose lanes are (slot, world) or (world, slot) pairs touches 64 distinct banks.
+constexpr int kVelOffsetWords = 2 * 8 * 3 * 32;            // 6 KiB: beyond the manifold slots and the hull AABBs
 struct alignas(16) OctRes {
     float pos[3][kNumDSlots][kTile];
     float rot[4][kNumDSlots][kTile];        // w, x, y, z
     float ppos[3][kNumDSlots][kTile];       // pose at the start of the substep
     float prot[4][kNumDSlots][kTile];
-    float lin[3][kNumDSlots][kTile];
-    float ang[3][kNumDSlots][kTile];
     int meta[kNumDSlots][kTile];            // meta_pack(); 0 = empty slot
     // Scratch of the broadphase / the convex tests.  The work list of the convex tests is written when the
     // broadphase loops are over (the walls are dead by then) and lies beyond the clip buffers that the convex
@@ -72,8 +76,21 @@ struct alignas(16) OctRes {
         struct {
             float clip[kClipWords];                                     // polygon clipping of the convex tests
             unsigned short items[kMaxItems + 32];                       // world << 6 | candidate (32+ = static); ramp items start at a multiple of 32
-            int pend[5][kClipLanes];                                    // colliding pairs waiting for contact generation: item, axis code, axis xyz
+            int pend[4][kClipLanes];                                    // colliding pairs waiting for contact generation: item | axis code << 16, axis xyz
         } sat;
+        // The velocities share the memory of the convex tests' scratch: between the integration of a substep (which consumes
+        // them) and the derivation of the new ones from the pose change (after the position solve) the velocity of a DYNAMIC
+        // body is dead, and that is exactly when the broadphase stages the walls and the convex tests clip their polygons
+        // here — which buys the scratch of 48 contact lanes per round instead of 32 (most substeps of the benchmark have
+        // about 32 colliding pairs per octet: one contact round instead of two).  The velocity of a body that is NOT
+        // dynamic (a locked box, an empty slot) is frozen (DESIGN.md "Engine decisions"); it is destroyed here and
+        // therefore never written back: copy_out_vel stores the rows of dynamic bodies only, HBM keeps the others.
+        // The manifold slots (clip words 0 .. 31 * 36) lie below the velocities and stay valid through the solver phases.
+        struct {
+            float pad[kVelOffsetWords];
+            float lin[3][kNumDSlots][kTile];
+            float ang[3][kNumDSlots][kTile];
+        } vel;
     } u;
     unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 5 | manifold location << 11 (pair_*() below)
     unsigned short scPair[kMaxSCand][kTile];    // body | static << 5 | location << 11  (static = wall index, 36 + plane index)
@@ -128,7 +145,7 @@ HSD void rst4(float (&a)[4][kNumDSlots][kTile], int slot, int g, Q q) { a[0][slo
 HSD void rbody_load(const OctRes &R, int g, int slot, BodyS &b) {
     b.pos = rld3(R.pos, slot, g); b.rot = rld4(R.rot, slot, g);
     b.ppos = rld3(R.ppos, slot, g); b.prot = rld4(R.prot, slot, g);
-    b.lin = rld3(R.lin, slot, g); b.ang = rld3(R.ang, slot, g);
+    b.lin = rld3(R.u.vel.lin, slot, g); b.ang = rld3(R.u.vel.ang, slot, g);
     const int m = R.meta[slot][g];
     const bool dyn = m != 0 && meta_resp(m) == RESP_DYNAMIC;
     b.invM = dyn ? obj_inv_mass(meta_obj(m)) : 0.f;
@@ -136,7 +153,7 @@ HSD void rbody_load(const OctRes &R, int g, int slot, BodyS &b) {
     body_refresh_inertia(b);
 }
 HSD void rbody_store_pose(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.pos, slot, g, b.pos); rst4(R.rot, slot, g, b.rot); }
-HSD void rbody_store_vel(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.lin, slot, g, b.lin); rst3(R.ang, slot, g, b.ang); }
+HSD void rbody_store_vel(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.u.vel.lin, slot, g, b.lin); rst3(R.u.vel.ang, slot, g, b.ang); }
 HSD void derive_velocity(BodyS &b) {
     const float h = kSubstepH;
     b.lin = (b.pos - b.ppos) * (1.f / h);
@@ -222,6 +239,17 @@ HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
     for (int i = threadIdx.x; i < ROWS * kTile / 4; i += 64) dst[i] = s[i];
 }
 
+// The velocity columns: only the rows of DYNAMIC bodies go back (OctRes::u.vel: the others were scratch during the step).
+template <typename OR>
+HSD void copy_out_vel(const Col<float, 3 * kNumDSlots> &col, int o, const float *src, const OR &R) {
+    float *dst = col.octet(o);
+    for (int i = threadIdx.x; i < 3 * kNumDSlots * kTile; i += 64) {
+        const int slot = (i >> 3) % kNumDSlots, g = i & 7;
+        const int m = R.meta[slot][g];
+        if (m != 0 && meta_resp(m) == RESP_DYNAMIC) dst[i] = src[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Start of a substep for one body: remember the pose, semi-implicit Euler step (gravity, agent force and
 // torque, gyroscopic term), refresh the hull AABB and the ground-plane manifold (registers of the body's lane).
@@ -240,7 +268,7 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta, const 
     V3 pos = rld3(R.pos, slot, g); Q rot = rld4(R.rot, slot, g);
     rst3(R.ppos, slot, g, pos); rst4(R.prot, slot, g, rot);
     if (dyn) {
-        V3 lin = rld3(R.lin, slot, g), ang = rld3(R.ang, slot, g);
+        V3 lin = rld3(R.u.vel.lin, slot, g), ang = rld3(R.u.vel.ang, slot, g);
         const float h = kSubstepH;
         const float invM = obj_inv_mass(obj);
         const V3 invI = obj_inv_inertia(obj);
@@ -254,7 +282,7 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta, const 
         ang = qrot(rot, wloc);
         rot = quat_add_rotation(rot, ang * h);
         rst3(R.pos, slot, g, pos); rst4(R.rot, slot, g, rot);
-        rst3(R.lin, slot, g, lin); rst3(R.ang, slot, g, ang);
+        rst3(R.u.vel.lin, slot, g, lin); rst3(R.u.vel.ang, slot, g, ang);
     }
     V3 lo, hi;
     const HullRef hb = hull_ref_body(obj, pos, rot);
@@ -420,7 +448,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
         if (spillDD || spillSC) spInfo[0] = tot_dd | (tot_sc << 16);
         R.ndd[g] = (unsigned char)min(tot_dd, kMaxDDCand); R.nsc[g] = (unsigned char)min(tot_sc, kMaxSCand);
         // what k_balance sorts the worlds by: candidate pairs are where an octet's time differs from another's
-        if (R.wid[g] >= 0 && tot_dd + tot_sc > 0) S.loadAcc[R.wid[g]] += tot_dd + tot_sc;
+        if (R.wid[g] >= 0 && tot_dd + tot_sc > 0) S.loadAcc[R.wid[g]] += HS_LOAD_DD_WEIGHT * tot_dd + tot_sc;
     }
     wave_sync();
     return ic;
@@ -461,7 +489,7 @@ HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
             const bool isdd = kind == 0;
             const int n = isdd ? tot & 0xffff : tot >> 16;
 #pragma unroll 1
-            for (int base = isdd ? kMaxDDCand : kMaxSCand; base < n; base += kClipLanes) {
+            for (int base = isdd ? kMaxDDCand : kMaxSCand; base < n; base += kSatPairs) {
                 const int kk = base + (lane >> 1);
                 if (kk < n) {
                     const int pair = c.spPair[(size_t)w * (kAllDD + kAllSC) + (isdd ? 0 : kAllDD) + kk];
@@ -615,10 +643,10 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
     bool wroteGlobal = false;
     int mw[kManWords]; int mkind = 0, mkk = 0, mg = 0, mpair = 0;      // the manifold for LDS: 1 body-body, 2 body-static
     if (lane < npend) {
-        const int item = R.u.sat.pend[0][lane];
+        const int item = R.u.sat.pend[0][lane] & 0xffff;
         AxisResult res;
-        res.code = R.u.sat.pend[1][lane];
-        res.ax = {__int_as_float(R.u.sat.pend[2][lane]), __int_as_float(R.u.sat.pend[3][lane]), __int_as_float(R.u.sat.pend[4][lane])};
+        res.code = R.u.sat.pend[0][lane] >> 16;
+        res.ax = {__int_as_float(R.u.sat.pend[1][lane]), __int_as_float(R.u.sat.pend[2][lane]), __int_as_float(R.u.sat.pend[3][lane])};
         const int g = item >> 6, idx = item & 63;
         const int w = S.wbeg + g;
         const bool isdd = idx < 32;
@@ -700,14 +728,14 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
 #endif
     // rounds over the box-only items, 2 lanes per pair and 32 pairs per round, then over the items with a wedge, 16 lanes
     // per pair and 4 pairs per round (sat_axes_wide); `lead`: the lane of a pair that files its result
-    const int boxRounds = (ic.nbox + kClipLanes - 1) / kClipLanes, wedgeRounds = (ic.nwedge + 3) / 4;
+    const int boxRounds = (ic.nbox + kSatPairs - 1) / kSatPairs, wedgeRounds = (ic.nwedge + 3) / 4;
     // (pairs beyond the LDS capacities, if any world of the octet has them: tested and turned into manifolds first, while
     // the clip buffers are free)
     if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_sat(spill_ctx(S), &R); usedGlobal = true; }
     for (int round = 0; round < boxRounds + wedgeRounds; ++round) {
         HS_SAT_T(const long long tr0_ = wall_clock64();)
         const bool wide = round >= boxRounds;
-        const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * kClipLanes;
+        const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * kSatPairs;
         const int it = wide ? base + (lane >> 4) : base + (lane >> 1);
         const bool lead = wide ? (lane & 15) == 0 : !hi;
         AxisResult res = {0, {0.f, 0.f, 0.f}};
@@ -756,8 +784,8 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
         nhit_total += nhit;
         if (hit) {
             const int pos = npend + __popcll(m & ((1ull << lane) - 1ull));
-            R.u.sat.pend[0][pos] = item; R.u.sat.pend[1][pos] = res.code;
-            R.u.sat.pend[2][pos] = __float_as_int(res.ax.x); R.u.sat.pend[3][pos] = __float_as_int(res.ax.y); R.u.sat.pend[4][pos] = __float_as_int(res.ax.z);
+            R.u.sat.pend[0][pos] = item | (res.code << 16);         // (item < 2^9, axis code < 2^12)
+            R.u.sat.pend[1][pos] = __float_as_int(res.ax.x); R.u.sat.pend[2][pos] = __float_as_int(res.ax.y); R.u.sat.pend[3][pos] = __float_as_int(res.ax.z);
         }
         npend += nhit;
     }
@@ -1063,11 +1091,7 @@ HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
     const V3 gn = -V3{R.plane0[0][g], R.plane0[1][g], R.plane0[2][g]};
     const float gmuS = 0.5f * (obj_mu_s(obj) + obj_mu_s(OBJ_PLANE));
     // agents are yaw-only bodies (obj_inv_inertia): their floor contacts share the manifold's normal multiplier
-#ifdef HS_EXP_NO_YAW
-    const bool yaw = false;
-#else
     const bool yaw = slot >= kAgentSlot0;
-#endif
     float dj[4] = {0.f, 0.f, 0.f, 0.f}, share = 0.f;
     if (yaw) share = yaw_ground_prepass(me, gn, b.np, hull_local_vertex(obj, b.vidx & 7), hull_local_vertex(obj, (b.vidx >> 3) & 7),
                                         hull_local_vertex(obj, (b.vidx >> 6) & 7), hull_local_vertex(obj, (b.vidx >> 9) & 7), kGroundOff, dj);
@@ -1174,11 +1198,7 @@ HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int sl
         }
         body_refresh_inertia(me);
         // the ground manifold of an agent (a yaw-only body): manifold-level normal part first (hs_solver.h)
-#ifdef HS_EXP_NO_YAW
-        const bool yaw = false;
-#else
         const bool yaw = POS && !walls && slot >= kAgentSlot0;
-#endif
         float dj[4] = {0.f, 0.f, 0.f, 0.f}, share = 0.f;
         if (yaw) share = yaw_ground_prepass(me, n, np, hull_local_vertex(obj, b.vidx & 7), hull_local_vertex(obj, (b.vidx >> 3) & 7),
                                             hull_local_vertex(obj, (b.vidx >> 6) & 7), hull_local_vertex(obj, (b.vidx >> 9) & 7), kGroundOff, dj);
@@ -1326,9 +1346,9 @@ HSD void phase_post(const SimState &S, OctRes &R) {
         if (l == 0) R.seen[g] = 0;
         if (instant && l < kMaxAgents && R.meta[kAgentSlot0 + l][g] != 0) {
             const int slot = kAgentSlot0 + l;
-            R.lin[0][slot][g] = 0.f; R.lin[1][slot][g] = 0.f;
-            R.lin[2][slot][g] = fminf(R.lin[2][slot][g], 0.f);
-            rst3(R.ang, slot, g, V3{0.f, 0.f, 0.f});
+            R.u.vel.lin[0][slot][g] = 0.f; R.u.vel.lin[1][slot][g] = 0.f;
+            R.u.vel.lin[2][slot][g] = fminf(R.u.vel.lin[2][slot][g], 0.f);
+            rst3(R.u.vel.ang, slot, g, V3{0.f, 0.f, 0.f});
         }
     }
     wave_sync();
@@ -1487,7 +1507,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
 #endif
     // ---- the octet's columns -> LDS (the blocks are contiguous; worlds beyond N are zero padding = empty slots)
     copy_in(&R.pos[0][0][0], S.bpos, o); copy_in(&R.rot[0][0][0], S.brot, o);
-    copy_in(&R.lin[0][0][0], S.blin, o); copy_in(&R.ang[0][0][0], S.bang, o);
+    copy_in(&R.u.vel.lin[0][0][0], S.blin, o); copy_in(&R.u.vel.ang[0][0][0], S.bang, o);
     copy_in(&R.meta[0][0], S.bmeta, o);
     if (L < kTile) {
         const int w = S.worldOfSlot[S.wbeg + L];      // which world lives in this slot (k_balance moves them)
@@ -1545,27 +1565,25 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     }
     wave_sync();
     HS_TICK(1)
+    // The substeps.  What follows the broadphase exists twice: the fast instantiation, and the one that knows the spill
+    // path, entered only for a substep in which a world of the octet has candidate pairs beyond the LDS capacities (a
+    // handful in millions of world-steps).  (Tried against the 12 registers this costs the hot path in spills — the step
+    // sits at its 256-register budget and the two instantiations share loop invariants that then live across both:
+    // the cold one as a real call, which constrains the allocation around it far more (93 spills); in a loop of its
+    // own that finishes the step (18); one instantiation with run-time branches (14).)
 #pragma unroll 1
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect<ROUNDS>(S, R, NS);
         HS_TICK(2)
-        // (the instantiation with the spill path only for a substep in which a world of the octet has candidate pairs
-        // beyond the LDS capacities: a handful in millions of world-steps)
-#ifdef HS_EXP_NO_SPILL
-        substep_rest<ROUNDS, false>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
-#elif defined(HS_SPILL_SINGLE)
-        substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
-#else
         if (__builtin_expect(ic.anySpill, 0)) substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
         else substep_rest<ROUNDS, false>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
-#endif
     }
 #undef HS_BODY
     phase_post(S, R);
     wave_sync();
     // ---- LDS -> the octet's columns
     copy_out(S.bpos, o, &R.pos[0][0][0]); copy_out(S.brot, o, &R.rot[0][0][0]);
-    copy_out(S.blin, o, &R.lin[0][0][0]); copy_out(S.bang, o, &R.ang[0][0][0]);
+    copy_out_vel(S.blin, o, &R.u.vel.lin[0][0][0], R); copy_out_vel(S.bang, o, &R.u.vel.ang[0][0][0], R);
     copy_out(S.bmeta, o, &R.meta[0][0]);
     mem_sync();                           // the write-back is complete before a regenerated level overwrites it
     HS_TICK(8)
