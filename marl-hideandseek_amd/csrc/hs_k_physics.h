@@ -623,6 +623,25 @@ HS_COLD void spill_static(SpillCtx c, OctRes *Rp, int NS) {
     }
 }
 
+#ifdef HS_PHASE_TIMING
+#define HS_TICK_PARAMS , long long &tk, long long (&acc)[10]
+#define HS_TICK_ARGS , tk, acc
+#define HS_TICK(i) { const long long now_ = wall_clock64(); acc[i] += now_ - tk; tk = now_; }
+#else
+#define HS_TICK_PARAMS
+#define HS_TICK_ARGS
+#define HS_TICK(i)
+#endif
+// HS_FINE_TIMING (with HS_PHASE_TIMING; development aid): the ten slots are re-assigned to look inside the convex tests —
+// 0 everything before them, 1 axis search of the box rounds, 2 of the wedge rounds, 3 pending-list upkeep, 4 contact
+// generation, 5 manifold records, 6 dd_pos, 7 static position passes, 8 the rest of the substep, 9 post / load / store.
+#ifdef HS_FINE_TIMING
+#define HS_FTICK(i) HS_TICK(i)
+#define HS_CTICK(i, j) HS_TICK(j)
+#else
+#define HS_FTICK(i)
+#define HS_CTICK(i, j) HS_TICK(i)
+#endif
 // ------------------------------------------------------------------------------------------
 // Exact convex tests, in two stages (hs_collide.h).  Stage 1 — the separating-axis search — runs over all the
 // octet's candidate pairs, two lanes per pair (2k and 2k + 1), 32 pairs per round; the pairs that collide are appended
@@ -637,7 +656,7 @@ HSD HullSrc sat_hull_b(const SimState &S, const OctRes &R, int g, int w, bool is
 }
 // stage 2 for the first `npend` pending pairs: lane i < 32 takes pair i.  `last`: this is the substep's last round,
 // whose manifolds stay in LDS (in the lane's own clip column); returns whether a manifold went to global memory.
-HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
+HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PARAMS) {
     const int lane = threadIdx.x & 63;
     const bool toLds = last && lane < kLocGlobal;
     bool wroteGlobal = false;
@@ -695,6 +714,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
     }
     // every lane is done with its clipping scratch: the slots may overwrite it
     wave_sync(); __builtin_amdgcn_wave_barrier();
+    HS_FTICK(4)
     if (mkind != 0) {
         int4 *dst = reinterpret_cast<int4 *>(R.u.sat.clip + lane * kManWords);
 #pragma unroll
@@ -708,12 +728,13 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last) {
         }
     }
     wave_sync();
+    HS_FTICK(5)
     return __ballot(wroteGlobal) != 0ull;
 }
 // Returns whether any manifold of the substep lies in the global workspace (wave-uniform): only then do the solver
 // phases have to wait for global memory at all.
 template <bool SPILL>
-HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
+HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     const int lane = threadIdx.x & 63;
     const bool hi = (lane & 1) != 0;                  // the second lane of a pair (box rounds: lanes 2k, 2k + 1)
@@ -776,11 +797,14 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
             }
         }
         HS_SAT_T(if (wide) twedge += wall_clock64() - tr0_;)
+#ifdef HS_FINE_TIMING
+        if (wide) HS_TICK(2) else HS_TICK(1)
+#endif
         // the colliding pairs of this round join the pending list (their lead lanes file the results)
         const bool hit = lead && res.code != 0;
         const unsigned long long m = __ballot(hit);
         const int nhit = __popcll(m);
-        if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, false); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
+        if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, false HS_TICK_ARGS); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
         nhit_total += nhit;
         if (hit) {
             const int pos = npend + __popcll(m & ((1ull << lane) - 1ull));
@@ -788,9 +812,10 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic) {
             R.u.sat.pend[1][pos] = __float_as_int(res.ax.x); R.u.sat.pend[2][pos] = __float_as_int(res.ax.y); R.u.sat.pend[3][pos] = __float_as_int(res.ax.z);
         }
         npend += nhit;
+        HS_FTICK(3)
     }
     wave_sync();
-    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, true); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; }
+    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, true HS_TICK_ARGS); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; }
     usedGlobal |= __ballot(planeMan) != 0ull;
     if (usedGlobal) mem_sync();          // the manifolds in global memory are complete for the lanes that solve them
 #ifdef HS_SAT_COUNTERS
@@ -1429,25 +1454,16 @@ HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int 
 
 // What follows the broadphase in a substep: convex tests -> body-body position solve -> static position passes ->
 // velocities from the pose change -> body-body and static velocity passes (-> integration for the next substep).
-#ifdef HS_PHASE_TIMING
-#define HS_TICK_PARAMS , long long &tk, long long (&acc)[10]
-#define HS_TICK_ARGS , tk, acc
-#define HS_TICK(i) { const long long now_ = wall_clock64(); acc[i] += now_ - tk; tk = now_; }
-#else
-#define HS_TICK_PARAMS
-#define HS_TICK_ARGS
-#define HS_TICK(i)
-#endif
 #define HS_BODY(r) const bool valid = (r) * 64 + L < nbodies; const int t_ = valid ? R.bodies[(r) * 64 + L] : 0; \
                    const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
 template <int ROUNDS, bool SPILL>
 HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int NS, ItemCounts ic, bool integrateNext,
                       const float *aforce HS_TICK_PARAMS) {
     const int L = threadIdx.x;
-    const bool manGlobal = phase_sat<SPILL>(S, R, ic);
-    HS_TICK(3)
+    const bool manGlobal = phase_sat<SPILL>(S, R, ic HS_TICK_ARGS);
+    HS_CTICK(3, 3)
     phase_dd<true, SPILL>(S, R, ic.anySpill);
-    HS_TICK(4)
+    HS_CTICK(4, 6)
     // (with 6 agents a third round exists for up to 136 bodies, but an octet rarely holds more than 128: then round 1 is
     // the last one that holds bodies, and the passes are two, not three)
     const bool shortLast = ROUNDS == 3 && nbodies <= 128;
@@ -1462,9 +1478,9 @@ HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int n
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) derive_body_velocity(R, slot, g, meta); }
     if (manGlobal) mem_sync(); else wave_sync();   // (the multipliers of manifolds in the global workspace, for the velocity pass)
-    HS_TICK(5)
+    HS_CTICK(5, 7)
     phase_dd<false, SPILL>(S, R, ic.anySpill);
-    HS_TICK(6)
+    HS_CTICK(6, 8)
     if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), false>(S, R, br, nbodies, nLast, nMerged);
     else static_passes<ROUNDS, ROUNDS - 1, false>(S, R, br, nbodies, nLast, nMerged);
     if (wl.nwb > nMerged) { wall_round<false>(S, R, nMerged, wl.nwb); wave_sync(); }
@@ -1474,7 +1490,7 @@ HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int n
         for (int r = 0; r < ROUNDS; ++r) { HS_BODY(r) if (valid) integrate_body(R, br[r], slot, g, meta, aforce); }
         wave_sync();
     }
-    HS_TICK(7)
+    HS_CTICK(7, 8)
 }
 
 // ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
@@ -1564,7 +1580,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         if (valid) integrate_body(R, b, slot, g, meta, aforce);
     }
     wave_sync();
-    HS_TICK(1)
+    HS_CTICK(1, 0)
     // The substeps.  What follows the broadphase exists twice: the fast instantiation, and the one that knows the spill
     // path, entered only for a substep in which a world of the octet has candidate pairs beyond the LDS capacities (a
     // handful in millions of world-steps).  (Tried against the 12 registers this costs the hot path in spills — the step
@@ -1574,7 +1590,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
 #pragma unroll 1
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect<ROUNDS>(S, R, NS);
-        HS_TICK(2)
+        HS_CTICK(2, 0)
         if (__builtin_expect(ic.anySpill, 0)) substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
         else substep_rest<ROUNDS, false>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
     }
@@ -1586,7 +1602,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     copy_out_vel(S.blin, o, &R.u.vel.lin[0][0][0], R); copy_out_vel(S.bang, o, &R.u.vel.ang[0][0][0], R);
     copy_out(S.bmeta, o, &R.meta[0][0]);
     mem_sync();                           // the write-back is complete before a regenerated level overwrites it
-    HS_TICK(8)
+    HS_CTICK(8, 9)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
     // (the generator works in the LDS the octet no longer needs: hs_k_reset.h GenScratch)
     {
