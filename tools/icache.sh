@@ -2,7 +2,7 @@
 # instruction-cache behaviour of the step kernels (SQC counters), sequential launches
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ic1
-HS_OVERLAP=0 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/ic1 -- python3 bench.py --steps 20 --warmup 100 --no-cpu-baseline > gpurun_out/ic1.log 2>&1 || { tail -5 gpurun_out/ic1.log; exit 1; }
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/ic1 -- python3 bench.py --steps 20 --warmup 100 --no-cpu-baseline > gpurun_out/ic1.log 2>&1 || { tail -5 gpurun_out/ic1.log; exit 1; }
 python3 - <<'PY'
 import csv, glob, collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()

@@ -1,5 +1,5 @@
 """What the slowest physics wave of a step spends its time on (development aid; needs the HS_PHASE_TIMING build):
-  HS_OVERLAP=0 HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so python tools/phase_tail.py [worlds] [steps]
+  HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so python tools/phase_tail.py [worlds] [steps]
 Per step the per-wave phase ticks are differenced; the table compares the mean wave with the slowest one."""
 import os, sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "marl-hideandseek_amd"))

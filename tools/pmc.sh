@@ -2,9 +2,6 @@
 # HBM traffic of the step kernels from rocprofv3 PMC counters (separate passes, kernel-trace only),
 # plus a calibration copy with the same access pattern (one coalesced dword per lane).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# counters are collected with the kernels of a step launched one after the other: the profiler serialises kernels, which the
-# dependency schedule (k_observe beside k_physics) must not be run under
-export HS_OVERLAP=0
 cat > /tmp/pmc_calib.py <<'PY'
 import ctypes, os
 L = ctypes.CDLL(os.path.join(os.environ["GRAFT_REPO_ROOT"], "marl-hideandseek_amd", "lib", "libhideseek.so"))

@@ -1,9 +1,6 @@
 #!/bin/bash
 # per-kernel SQ counters (waves, instruction mix, busy/wait cycles, instruction fetch, LDS) of the benchmark step
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# counters are collected with the kernels of a step launched one after the other: the profiler serialises kernels, which the
-# dependency schedule (k_observe beside k_physics) must not be run under
-export HS_OVERLAP=0
 rm -rf gpurun_out/sq1 gpurun_out/sq2 gpurun_out/sq3 gpurun_out/sq4
 run() { d=$1; shift; timeout -k 5 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/$d -- python3 bench.py --steps 20 --warmup 100 --no-cpu-baseline > gpurun_out/$d.log 2>&1 || { tail -5 gpurun_out/$d.log; exit 1; }; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SMEM
