@@ -121,10 +121,11 @@ void launch_observe(hs_sim *s, hipStream_t strm) {
 // One step = k_physics (movement + actionSystem, 4 XPBD substeps, rewards / dones / episode results, reset: one
 // kernel, a wave per octet of 8 worlds, hs_k_physics.h) and k_observe.  Manager::init = k_reset then k_observe.
 // `stages`: 1 physics, 2 reset (init only), 4 observe.
-int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7) {
+int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int stages = 7, bool capture = false) {
     hs::SimState S = s->S;
     const int N = S.N, noct = (N + hs::kTile - 1) / hs::kTile;
-    S.stepIdx = s->step_idx; if (!first && (stages & 1)) s->step_idx = (s->step_idx + 1) % 3;
+    // (a captured launch keeps its arguments for ever: it gets no step index, and the kernel skips the per-wave priority hint)
+    S.stepIdx = capture ? -1 : s->step_idx; if (!capture && !first && (stages & 1)) s->step_idx = (s->step_idx + 1) % 3;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first && (stages & 1)) {
         // 17 body slots x 8 worlds need a third round of 64 lanes only with 6 agents per world
@@ -192,7 +193,7 @@ int launch_step(hs_sim *s, hipStream_t strm, bool first) {
         for (int g = 0; g < ngraphs && ok; ++g) {
             hipGraph_t gr = nullptr;
             ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) ok = launch_step_eager(s, cap, false, false, g == 0 ? 1 : 4) == HS_OK;
+            if (ok) ok = launch_step_eager(s, cap, false, false, g == 0 ? 1 : 4, true) == HS_OK;
             if (hipStreamEndCapture(cap, &gr) != hipSuccess) ok = false;
             if (ok) ok = hipGraphInstantiate(&s->graph_exec[g], gr, nullptr, nullptr, 0) == hipSuccess;
             if (gr) hipGraphDestroy(gr);

@@ -465,7 +465,7 @@ HSD AxisCand axis_reduce16(AxisCand c) {
 }
 HSD bool group16_any(bool x) {
     const unsigned long long b = __ballot(x);
-    return ((b >> (threadIdx.x & 48)) & 0xffffull) != 0ull;
+    return ((b >> (hs_lane() & 48)) & 0xffffull) != 0ull;
 }
 HSD AxisResult sat_axes_wide(const HullSrc &sa, const HullSrc &sb, const int part) {
     AxisResult res = {0, {0.f, 0.f, 0.f}};
@@ -509,7 +509,7 @@ HSD AxisResult sat_axes_wide(const HullSrc &sa, const HullSrc &sb, const int par
         if (group16_any(have && s > 0.f)) return res;
         const AxisCand ce = axis_reduce16(AxisCand{have ? s : kNone, have ? part : 99});
         if (ce.i != 99) {
-            const int src = (threadIdx.x & 48) + ce.i;
+            const int src = (hs_lane() & 48) + ce.i;
             bestE = ce.s; ea = ce.i / bned; eb = ce.i - ea * bned;
             axE = {__shfl(ax.x, src), __shfl(ax.y, src), __shfl(ax.z, src)};
         }

@@ -12,6 +12,15 @@
 
 #define HSD __device__ __forceinline__
 
+// The lane index as the physics kernel reads it: an OPAQUE copy of threadIdx.x.  k_physics is one function of ~60 000
+// instructions whose phases each derive a dozen lane constants (world = lane / 8, LDS offsets of its rows, ...).  Given
+// the plain threadIdx.x the compiler computes them all once at the top of the kernel and keeps them alive through the
+// substep loop — some forty registers of loop invariants in a kernel that sits at the 256-register budget of two waves
+// per SIMD (12 spilled dwords, 52 B of scratch per lane).  An empty asm makes every call a value of its own: each phase
+// re-derives its constants (a few integer instructions) and nothing lives across phases: 223 registers, no spill, no
+// scratch.
+__device__ __forceinline__ int hs_lane() { int x = threadIdx.x; asm volatile("" : "+v"(x)); return x; }
+
 namespace hs {
 
 // ---- capacities and constants: src/sim.hpp:39-41, src/sim.cpp:14-17 ----

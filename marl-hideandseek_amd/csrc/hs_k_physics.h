@@ -229,21 +229,21 @@ HSD void copy_in(T *dst, const Col<T, ROWS> &col, int o) {
     static_assert(sizeof(T) == 4 && (ROWS * kTile) % 4 == 0, "16-byte pieces");
     const float4 *src = reinterpret_cast<const float4 *>(col.octet(o));
     float4 *d = reinterpret_cast<float4 *>(dst);
-    for (int i = threadIdx.x; i < ROWS * kTile / 4; i += 64) d[i] = src[i];
+    for (int i = hs_lane(); i < ROWS * kTile / 4; i += 64) d[i] = src[i];
 }
 template <typename T, int ROWS>
 HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
     static_assert(sizeof(T) == 4 && (ROWS * kTile) % 4 == 0, "16-byte pieces");
     float4 *dst = reinterpret_cast<float4 *>(col.octet(o));
     const float4 *s = reinterpret_cast<const float4 *>(src);
-    for (int i = threadIdx.x; i < ROWS * kTile / 4; i += 64) dst[i] = s[i];
+    for (int i = hs_lane(); i < ROWS * kTile / 4; i += 64) dst[i] = s[i];
 }
 
 // The velocity columns: only the rows of DYNAMIC bodies go back (OctRes::u.vel: the others were scratch during the step).
 template <typename OR>
 HSD void copy_out_vel(const Col<float, 3 * kNumDSlots> &col, int o, const float *src, const OR &R) {
     float *dst = col.octet(o);
-    for (int i = threadIdx.x; i < 3 * kNumDSlots * kTile; i += 64) {
+    for (int i = hs_lane(); i < 3 * kNumDSlots * kTile; i += 64) {
         const int slot = (i >> 3) % kNumDSlots, g = i & 7;
         const int m = R.meta[slot][g];
         if (m != 0 && meta_resp(m) == RESP_DYNAMIC) dst[i] = src[i];
@@ -307,7 +307,7 @@ struct ItemCounts { int nbox, nwedge; bool anySpill; };
 template <int JB>            // body slots per lane: 2 covers 16 slots (<= 5 agents), 3 all 17
 HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
     constexpr int G = 8;
-    const int L = threadIdx.x, g = L / G, l = L % G;
+    const int L = hs_lane(), g = L / G, l = L % G;
     const int o = blockIdx.x;
     // the octet's walls -> LDS, 16 bytes per lane and component (rows beyond a world's count are never read)
     {
@@ -456,10 +456,7 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
 
 // ------------------------------------------------------------------------------------------
 // The SPILL PATH: candidate pairs beyond the LDS capacities.  Cold code behind wave-uniform branches.
-// The step's hot path sits exactly at the 256-register budget of two waves per SIMD, and any code that shares a
-// function with it — even behind a branch that is never taken — moves its register allocation.  So the rest of a substep
-// exists TWICE (substep_rest<ROUNDS, SPILL>): the fast instantiation contains nothing of what follows, and the
-// instantiation with SPILL is entered, after the broadphase, only for a substep in which a world of the octet spills.
+// (Template parameter SPILL of the phases: false compiles the spill path out — the register report of the fast path alone.)
 #define HS_COLD __device__ __forceinline__
 struct SpillCtx {
     const float *walls, *planes;         // the tiled columns (hs_state.h Col)
@@ -473,7 +470,7 @@ HSD SpillCtx spill_ctx(const SimState &S) { return {S.walls.p, S.planes.p, (ManD
 // is the rare path).  Every spilled pair gets a record at its place of the workspace; np = 0 says "no manifold".
 HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
     OctRes &R = *Rp;
-    const int lane = threadIdx.x & 63;
+    const int lane = hs_lane() & 63;
     const bool hi = (lane & 1) != 0;
     const Col<float, 4 * kMaxWalls> walls = {const_cast<float *>(c.walls)};
     const Col<float, 4 * kMaxPlanes> planes = {const_cast<float *>(c.planes)};
@@ -563,7 +560,7 @@ HS_COLD void spill_dd(SpillCtx c, OctRes *Rp) {
         if ((__builtin_amdgcn_readfirstlane((int)R.spill[g]) & 1) == 0) continue;
         const int w = c.wbeg + g;
         const int nall = __builtin_amdgcn_readfirstlane(c.spInfo[(size_t)w * kSpInfoWords]) & 0xffff;
-        if (threadIdx.x == 0) {
+        if (hs_lane() == 0) {
 #pragma unroll 1
             for (int k = kMaxDDCand; k < nall; ++k) {
                 ManDD *const m = c.wsDD + (size_t)w * kAllDD + k;       // (read field by field: a private copy indexed by j would live in scratch memory)
@@ -597,7 +594,7 @@ HS_COLD void spill_static(SpillCtx c, OctRes *Rp, int NS) {
     for (int g = 0; g < kTile; ++g) {
         if ((__builtin_amdgcn_readfirstlane((int)R.spill[g]) & 2) == 0) continue;
         const int w = c.wbeg + g;
-        const int slot = threadIdx.x;
+        const int slot = hs_lane();
         if (slot >= NS) continue;
         const int info = c.spInfo[(size_t)w * kSpInfoWords + 1 + slot];
         const int first = info & 0xffff, cnt = info >> 16;
@@ -657,7 +654,7 @@ HSD HullSrc sat_hull_b(const SimState &S, const OctRes &R, int g, int w, bool is
 // stage 2 for the first `npend` pending pairs: lane i < 32 takes pair i.  `last`: this is the substep's last round,
 // whose manifolds stay in LDS (in the lane's own clip column); returns whether a manifold went to global memory.
 HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PARAMS) {
-    const int lane = threadIdx.x & 63;
+    const int lane = hs_lane() & 63;
     const bool toLds = last && lane < kLocGlobal;
     bool wroteGlobal = false;
     int mw[kManWords]; int mkind = 0, mkk = 0, mg = 0, mpair = 0;      // the manifold for LDS: 1 body-body, 2 body-static
@@ -736,7 +733,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PA
 template <bool SPILL>
 HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
-    const int lane = threadIdx.x & 63;
+    const int lane = hs_lane() & 63;
     const bool hi = (lane & 1) != 0;                  // the second lane of a pair (box rounds: lanes 2k, 2k + 1)
     int npend = 0;
     bool usedGlobal = false, planeMan = false;
@@ -960,7 +957,7 @@ HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float
 template <bool POS, bool SPILL>
 HSD void phase_dd(const SimState &S, OctRes &R, bool anySpill) {
     constexpr int GL = 8, PAIRS = GL / 2;
-    const int L = threadIdx.x, g = L / GL, q = L % GL;
+    const int L = hs_lane(), g = L / GL, q = L % GL;
     const int h = q >> 1;                                         // this lane's pair within the world's 8 lanes
     const bool isA = (q & 1) == 0;
     const int gbit0 = g * GL;                                     // first lane of this group in the wave
@@ -1091,7 +1088,7 @@ HSD void phase_dd(const SimState &S, OctRes &R, bool anySpill) {
 struct WallLists { int nwb, nEarly; };     // listed bodies; how many of them belong to a round before the last one
 template <int ROUNDS>
 HSD WallLists list_wall_bodies(OctRes &R, int nbodies, int lastRound) {
-    const int L = threadIdx.x;
+    const int L = hs_lane();
     int n = 0, nEarly = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -1142,7 +1139,7 @@ HSD void ground_vel(OctRes &R, const BodyReg &b, int slot, int g, int meta) {
 // The wall / extra-plane manifolds of the listed bodies, one lane per body, candidates in solve order.
 template <bool POS>
 HSD void wall_round(const SimState &S, OctRes &R, int first, int nwb) {
-    for (int i = first + threadIdx.x; i < nwb; i += 64) {
+    for (int i = first + hs_lane(); i < nwb; i += 64) {
         const int t = R.wallBodies[i];
         const int slot = t >> 3, g = t & 7;
         const int sci = R.scInfo[slot][g];
@@ -1188,7 +1185,7 @@ HSD void wall_round(const SimState &S, OctRes &R, int first, int nwb) {
 // is left to wall_round.  Per body the order stays ground, then its static candidates by index.
 template <bool POS>
 HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int slot, int g, int meta, int nLast, int nMerged) {
-    const int mi = (int)threadIdx.x - nLast;
+    const int mi = (int)hs_lane() - nLast;
     const bool walls = mi >= 0 && mi < nMerged;
     unsigned todo = 0u; int bsc = 0;
     if (walls) {
@@ -1313,7 +1310,7 @@ HSD void action_system(const SimState &S, OctRes &R, int g, int A_, int teams) {
 // A lane per (agent, world) maps the action row to a force; a lane per world then runs the action system for the
 // worlds in which an agent locks or grabs (scripts/benchmark.py never does, scripts/jax_train.py does all the time).
 HSD void phase_pre(const SimState &S, OctRes &R) {
-    const int A_ = S.A, L = threadIdx.x;
+    const int A_ = S.A, L = hs_lane();
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     bool need_action = false;
     if (L < kMaxAgents * kTile) {
@@ -1360,7 +1357,7 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
 // outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893).  8 lanes per world.
 HSD void phase_post(const SimState &S, OctRes &R) {
     constexpr int G = 8;
-    const int L = threadIdx.x, g = L / G, l = L % G;
+    const int L = hs_lane(), g = L / G, l = L % G;
     const int w = R.wid[g], p = S.wbeg + g;          // world id (exports, per-world scalars) / slot (columns)
     const int A_ = S.A;
     const bool wok = w >= 0;
@@ -1436,7 +1433,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
 // LASTR (the last round that holds bodies) with the wall manifolds of earlier rounds' bodies in its idle lanes.
 template <int ROUNDS, int LASTR, bool POS>
 HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int nLast, int nMerged) {
-    const int L = threadIdx.x;
+    const int L = hs_lane();
 #pragma unroll
     for (int r = 0; r < LASTR; ++r) {
         const bool valid = r * 64 + L < nbodies; const int t_ = valid ? R.bodies[r * 64 + L] : 0;
@@ -1459,7 +1456,7 @@ HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int 
 template <int ROUNDS, bool SPILL>
 HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int NS, ItemCounts ic, bool integrateNext,
                       const float *aforce HS_TICK_PARAMS) {
-    const int L = threadIdx.x;
+    const int L = hs_lane();
     const bool manGlobal = phase_sat<SPILL>(S, R, ic HS_TICK_ARGS);
     HS_CTICK(3, 3)
     phase_dd<true, SPILL>(S, R, ic.anySpill);
@@ -1497,7 +1494,7 @@ HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int n
 // 6 agents (17 slots x 8 worlds = 136 bodies at most).
 template <int ROUNDS>
 HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
-    const int L = threadIdx.x, o = blockIdx.x;
+    const int L = hs_lane(), o = blockIdx.x;
     S.wbeg = o * kTile;                               // first slot of the octet in the tiled columns
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
     const int noct = gridDim.x;
@@ -1506,7 +1503,9 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     // Measured: k_physics 0.387 -> 0.380 ms; boosting a wave while it is inside a chain of manifolds or an extra round
     // of convex tests instead gave 0.382.
     const long long tStart = wall_clock64();
-    {
+    // (S.stepIdx < 0: a launch replayed from a HIP graph, whose arguments are frozen at capture — no rotating sums, no hint)
+    if (S.stepIdx < 0) __builtin_amdgcn_s_setprio(2);
+    else {
         const int sidx = S.stepIdx, prevIdx = sidx == 0 ? 2 : sidx - 1, nextIdx = sidx == 2 ? 0 : sidx + 1;
         if (o == 0 && L == 0) S.tickSum[nextIdx] = 0ull;
         const float mean = (float)S.tickSum[prevIdx] / (float)noct, mine = (float)S.octTicks[o];
@@ -1581,18 +1580,17 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     }
     wave_sync();
     HS_CTICK(1, 0)
-    // The substeps.  What follows the broadphase exists twice: the fast instantiation, and the one that knows the spill
-    // path, entered only for a substep in which a world of the octet has candidate pairs beyond the LDS capacities (a
-    // handful in millions of world-steps).  (Tried against the 12 registers this costs the hot path in spills — the step
-    // sits at its 256-register budget and the two instantiations share loop invariants that then live across both:
-    // the cold one as a real call, which constrains the allocation around it far more (93 spills); in a loop of its
-    // own that finishes the step (18); one instantiation with run-time branches (14).)
+    // The substeps.  (The spill path — pairs beyond the LDS capacities, a handful in millions of world-steps — sits behind
+    // wave-uniform branches on ic.anySpill inside the phases.  While the kernel kept its lane constants alive across all
+    // phases it sat at its 256-register budget and this code cost the hot path 12 spilled registers whichever way it was
+    // packaged: as a second instantiation of the substep entered only when a world spills (12), in a loop of its own that
+    // finishes the step (18), as a real call (93).  With the opaque lane index — hs_dev.h hs_lane() — the kernel needs 221
+    // registers and the plain form spills nothing.)
 #pragma unroll 1
     for (int sub = 0; sub < kNumSubsteps; ++sub) {
         const ItemCounts ic = phase_detect<ROUNDS>(S, R, NS);
-        HS_CTICK(2, 0)
-        if (__builtin_expect(ic.anySpill, 0)) substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
-        else substep_rest<ROUNDS, false>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
+        HS_TICK(2)
+        substep_rest<ROUNDS, true>(S, R, br, nbodies, NS, ic, sub + 1 < kNumSubsteps, aforce HS_TICK_ARGS);
     }
 #undef HS_BODY
     phase_post(S, R);
@@ -1614,7 +1612,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
             reset_world(S, myWorld, gen[L]);
         }
     }
-    if (L == 0) {
+    if (L == 0 && S.stepIdx >= 0) {
         const int dt = (int)(wall_clock64() - tStart);
         S.octTicks[o] = dt;
         atomicAdd(&S.tickSum[S.stepIdx], (unsigned long long)dt);

@@ -67,6 +67,7 @@ def train_interface():
 
 
 _live_sims = weakref.WeakSet()
+_xla_registered = False          # sim.jax() registers the four XLA custom-call targets once per process
 
 
 @atexit.register
@@ -270,7 +271,9 @@ class HideAndSeekSimulator:
             raise NotImplementedError("sim.jax(jax_gpu=False): there is no CPU execution path (DESIGN.md §1)")
         bundle = {"train_interface": self.train_interface(), "targets": self.xla_custom_call_targets(),
                   "opaque": self.xla_opaque(), "signatures": self.xla_call_signatures(),
-                  "target_names": {k: f"gpu_hideseek_{k}_{id(self):x}" for k in _native.XLA_TARGETS}}
+                  # one set of names per process: the targets are the same native functions for every simulator,
+                  # the opaque descriptor says which one is meant
+                  "target_names": {k: f"gpu_hideseek_{k}" for k in _native.XLA_TARGETS}}
         try:
             from jax.lib import xla_client
         except ImportError:
@@ -283,8 +286,11 @@ class HideAndSeekSimulator:
             err.train_interface = bundle["train_interface"]
             err.xla = bundle
             raise err
-        for k, cap in bundle["targets"].items():
-            xla_client.register_custom_call_target(bundle["target_names"][k], cap, platform="ROCM")
+        global _xla_registered
+        if not _xla_registered:
+            for k, cap in bundle["targets"].items():
+                xla_client.register_custom_call_target(bundle["target_names"][k], cap, platform="ROCM")
+            _xla_registered = True
         return bundle
 
     def device_status(self):

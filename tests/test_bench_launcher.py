@@ -91,3 +91,17 @@ def test_one_rank_through_the_launcher_path():
     assert out["device_status"]["dropped_candidate_pairs"] == 0
     assert len(out["ms_per_step_per_rank"]) == 1 and "p50" in out["ms_per_step_percentiles"]
     assert "traffic_source" in out["roofline"]
+
+
+@pytest.mark.gpu
+def test_two_real_ranks_rehearsed_on_one_gpu():
+    """The whole N > 1 path with the product in it: HS_BENCH_REHEARSE=1 maps both ranks to GPU 0 and uses gloo for the
+    barrier / reductions (RCCL refuses two ranks on one device).  Two simulators with world offsets 0 and 1024 step side
+    by side; the line counts both ranks and both shards' worlds.  Not a scaling number — plumbing with real simulators."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "12", "--warmup", "2", "--worlds-per-gpu", "1024",
+                        "--no-cpu-baseline"], env=_env(HS_BENCH_REHEARSE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["total_worlds"] == 2048 and out["scaling"] == "weak"
+    assert len(out["ms_per_step_per_rank"]) == 2 and out["cpu_baseline"] is None if "cpu_baseline" in out else True
+    assert abs(out["value"] - 2048 * 12 / (out["ms_per_step"] * 12 * 1e-3)) < 1e-3 * out["value"]
