@@ -671,9 +671,18 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PA
         const int a = pair_a(pair), bsel = pair_b(pair);
         const ClipBuf cb = {R.u.sat.clip, lane};
         RawManifold raw;
-        if (sat_contact(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), res, cb, raw)) {
+        const bool plane = res.code == 3;                 // an extra plane of a debug level (static candidate kMaxWalls + p)
+        bool have;
+        if (plane) {
+            const int p = bsel - kMaxWalls;
+            const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
+            have = collide_hull_plane(hull_ref_body(meta_obj(R.meta[a][g]), rld3(R.pos, a, g), rld4(R.rot, a, g)), pn, S.planes(3 * kMaxPlanes + p, w), raw);
+        } else {
+            have = sat_contact(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), res, cb, raw);
+        }
+        if (have) {
             const int oa = meta_obj(R.meta[a][g]);
-            const int ob = isdd ? meta_obj(R.meta[bsel][g]) : OBJ_WALL;
+            const int ob = isdd ? meta_obj(R.meta[bsel][g]) : plane ? OBJ_PLANE : OBJ_WALL;
             const V3 pa = rld3(R.pos, a, g);
             const Q qai = qinv(rld4(R.rot, a, g));
             const float muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(ob)), muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(ob));
@@ -700,7 +709,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PA
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool on = j < raw.np;
-                    st3(m.rA[j], on ? qrot(qai, raw.pA[j] - pa) : V3{0.f, 0.f, 0.f});
+                    st3(m.rA[j], !on ? V3{0.f, 0.f, 0.f} : plane ? hull_local_vertex(oa, raw.vidx[j]) : qrot(qai, raw.pA[j] - pa));
                     m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
                 }
                 if (toLds) { __builtin_memcpy(mw, &m, sizeof(m)); mkind = 2; mkk = kk; mg = g; mpair = pair; }
@@ -736,7 +745,7 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
     const int lane = hs_lane() & 63;
     const bool hi = (lane & 1) != 0;                  // the second lane of a pair (box rounds: lanes 2k, 2k + 1)
     int npend = 0;
-    bool usedGlobal = false, planeMan = false;
+    bool usedGlobal = false;
     int nhit_total = 0, nflush = 0;      // (counters of the HS_PHASE_TIMING build)
 #ifdef HS_SAT_COUNTERS
     long long tflush = 0, twedge = 0; const long long tsat0 = wall_clock64();
@@ -750,9 +759,19 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
     // (pairs beyond the LDS capacities, if any world of the octet has them: tested and turned into manifolds first, while
     // the clip buffers are free)
     if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_sat(spill_ctx(S), &R); usedGlobal = true; }
-    for (int round = 0; round < boxRounds + wedgeRounds; ++round) {
+    // The axis-search rounds and the contact rounds alternate as two plain loops — as many axis-search rounds as the pending
+    // list (kClipLanes entries) is sure to hold, then one contact round — instead of a contact round nested inside the
+    // axis-search loop: the two bodies never share registers.  (A round files at most as many pairs as it has items.)
+    const int totalRounds = boxRounds + wedgeRounds;
+    int round = 0;
+    while (round < totalRounds) {
+    for (; round < totalRounds; ++round) {
         HS_SAT_T(const long long tr0_ = wall_clock64();)
         const bool wide = round >= boxRounds;
+        {
+            const int itemsHere = wide ? min(4, wedge0 + ic.nwedge - (wedge0 + (round - boxRounds) * 4)) : min(kSatPairs, ic.nbox - round * kSatPairs);
+            if (npend + itemsHere > kClipLanes) break;            // (the pending list goes through a contact round first)
+        }
         const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * kSatPairs;
         const int it = wide ? base + (lane >> 4) : base + (lane >> 1);
         const bool lead = wide ? (lane & 15) == 0 : !hi;
@@ -767,26 +786,8 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
             const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
             const int a = pair_a(pair), bsel = pair_b(pair);
             if (!isdd && bsel >= kMaxWalls) {
-                // extra planes (debug levels only): hull against plane, no axis search
-                const int oa = meta_obj(R.meta[a][g]);
-                const int p = bsel - kMaxWalls;
-                const V3 pn = {S.planes(0 * kMaxPlanes + p, w), S.planes(1 * kMaxPlanes + p, w), S.planes(2 * kMaxPlanes + p, w)};
-                RawManifold raw;
-                if (lead && collide_hull_plane(hull_ref_body(oa, rld3(R.pos, a, g), rld4(R.rot, a, g)), pn, S.planes(3 * kMaxPlanes + p, w), raw)) {
-                    ManS m;
-                    m.np = raw.np; st3(m.n, raw.n); m.pad[0] = 0.f; m.pad[1] = 0.f;
-                    m.muS = 0.5f * (obj_mu_s(oa) + obj_mu_s(OBJ_PLANE));
-                    m.muD = 0.5f * (obj_mu_d(oa) + obj_mu_d(OBJ_PLANE));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool on = j < raw.np;
-                        st3(m.rA[j], on ? hull_local_vertex(oa, raw.vidx[j]) : V3{0.f, 0.f, 0.f});
-                        m.offB[j] = on ? dot(raw.pB[j], raw.n) : 0.f; m.lam[j] = 0.f;
-                    }
-                    ((ManS *)S.wsSC + (size_t)w * kAllSC)[kk] = m;
-                    atomicOr(&R.scAcc[g], 1u << kk);
-                    planeMan = true;
-                }
+                // extra planes (debug levels only): no axis search — the contact round tests the hull against the plane
+                if (lead) res.code = 3;
             } else if (wide) {
                 res = sat_axes_wide(sat_hull_a(R, g, a), sat_hull_b(S, R, g, w, isdd, bsel), lane & 15);
             } else {
@@ -801,7 +802,6 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
         const bool hit = lead && res.code != 0;
         const unsigned long long m = __ballot(hit);
         const int nhit = __popcll(m);
-        if (npend + nhit > kClipLanes) { wave_sync(); HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, false HS_TICK_ARGS); HS_SAT_T(tflush += wall_clock64() - t0_;) npend = 0; ++nflush; }
         nhit_total += nhit;
         if (hit) {
             const int pos = npend + __popcll(m & ((1ull << lane) - 1ull));
@@ -812,8 +812,8 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
         HS_FTICK(3)
     }
     wave_sync();
-    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, true HS_TICK_ARGS); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; }
-    usedGlobal |= __ballot(planeMan) != 0ull;
+    if (npend > 0) { HS_SAT_T(const long long t0_ = wall_clock64();) usedGlobal |= sat_flush(S, R, npend, round >= totalRounds HS_TICK_ARGS); HS_SAT_T(tflush += wall_clock64() - t0_;) ++nflush; npend = 0; }
+    }
     if (usedGlobal) mem_sync();          // the manifolds in global memory are complete for the lanes that solve them
 #ifdef HS_SAT_COUNTERS
     if (lane == 0) {      // work counters of the convex tests (tools/phase_timing.py; their atomics disturb the phase times)
