@@ -186,6 +186,8 @@ def main():
                     help="16000 = BASELINE configs[1] (default); 16384 = one rank of configs[3] (131072 worlds over 8 GPUs)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-preroll", action="store_true",
+                    help="time the steps right after the warm-up even in a run shorter than an episode (a preparation-phase window)")
     ap.add_argument("--cpu-seconds", type=float, default=45.0,
                     help="time budget of the cpu_baseline leg (2000 worlds x 1920 steps take about 25 s on 16 threads)")
     ap.add_argument("--profile-every", type=int, default=0,
@@ -251,6 +253,17 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    # A run shorter than an episode sees only the part of it the window falls in, and the two parts differ: in the 95
+    # preparation steps two of the four agents are frozen (k_physics 0.36 ms), afterwards all four push things around
+    # (0.49 ms).  Right after the warm-up a short window — the driver's 20 steps — would be preparation phase only, i.e.
+    # 20 % better than the run over whole episodes.  Short runs are therefore moved, by untimed steps, to where the window
+    # holds the two phases in the episode's own proportion (95 : 145); runs of 240 steps or more start right away.
+    preroll = 0
+    if args.steps < 240 and not args.no_preroll:
+        first = (95 - round(args.steps * 95 / 240)) % 240          # first timed episode step
+        preroll = (first - args.warmup) % 240
+        for _ in range(preroll):
+            one_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -376,11 +389,15 @@ def main():
             "agent_steps_per_sec": total_worlds * A * args.steps / dt,
             # which part of the 240-step episode the timed window covers (every world is in lock-step): steps < 95
             # are the preparation phase (seekers frozen, no reward rays), every 240th step regenerates all levels
-            "episode_steps_covered": {"first": args.warmup % 240, "count": args.steps,
-                                      "level_regenerations": (args.warmup % 240 + args.steps) // 240,
-                                      "note": "a window inside [0, 95) is preparation phase only"
-                                      if args.warmup % 240 + args.steps <= 95 else "covers all phases of an episode"
-                                      if args.steps >= 240 else "partial episode"},
+            "episode_steps_covered": {"first": (args.warmup + preroll) % 240, "count": args.steps,
+                                      "untimed_steps_before": {"warmup": args.warmup, "preroll": preroll},
+                                      "preparation_steps_in_window": sum(1 for i in range(args.steps) if (args.warmup + preroll + i) % 240 < 95),
+                                      "level_regenerations": ((args.warmup + preroll) % 240 + args.steps) // 240,
+                                      "note": "whole episodes" if args.steps >= 240 else
+                                      ("a preparation-phase window (two of four agents frozen): about 20 % faster than whole episodes"
+                                       if (args.warmup + preroll) % 240 + args.steps <= 95 else
+                                       "shorter than an episode: moved by untimed preroll steps so that preparation and "
+                                       "post-preparation steps are in the episode's own proportion (95 : 145); no level regeneration inside")},
             "roofline": roofline,
         }
         out["device_status"] = status
