@@ -129,8 +129,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first && (stages & 1)) {
         // 17 body slots x 8 worlds need a third round of 64 lanes only with 6 agents per world
-        if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3(noct), dim3(hs::kPhysThreads), 0, strm, S);
-        else hipLaunchKernelGGL(hs::k_physics<2>, dim3(noct), dim3(hs::kPhysThreads), 0, strm, S);
+        if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3(noct), dim3(hs::kPhysThreads), hs::kPhysDynLds, strm, S);
+        else hipLaunchKernelGGL(hs::k_physics<2>, dim3(noct), dim3(hs::kPhysThreads), hs::kPhysDynLds, strm, S);
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own

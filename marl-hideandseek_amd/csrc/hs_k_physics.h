@@ -37,6 +37,11 @@
 namespace hs {
 
 constexpr int kPhysThreads = 64;                   // one wave
+#ifdef HS_EXP_REGCAP
+constexpr int kPhysDynLds = 20 * 1024;
+#else
+constexpr int kPhysDynLds = 0;
+#endif
 constexpr int kPhysWorlds = kTile;                 // worlds per workgroup
 constexpr int kMaxItems = kTile * (kMaxDDCand + kMaxSCand);        // convex-test items of an octet
 constexpr int kLdsWalls = 32;                      // walls per world staged in LDS for the broadphase (a world has
@@ -1623,11 +1628,21 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
 #undef HS_TICK
 }
 
+// -DHS_EXP_REGCAP=W (development aid): the kernel under the register budget of W waves per SIMD — the LDS becomes a dynamic
+// allocation (with the static 20 KiB the compiler knows that W > 2 is unattainable and ignores the request); occupancy on the
+// part stays at two waves per SIMD (LDS), so what the run shows is the cost of the spills alone.
 template <int ROUNDS>
+#ifdef HS_EXP_REGCAP
+__global__ void __launch_bounds__(kPhysThreads) __attribute__((amdgpu_waves_per_eu(HS_EXP_REGCAP, HS_EXP_REGCAP))) k_physics(SimState S) {
+    union PhysLds { OctRes R; GenScratch gen[kTile]; };
+    extern __shared__ __attribute__((aligned(16))) char dynlds[];
+    PhysLds &lds = *reinterpret_cast<PhysLds *>(dynlds);
+#else
 __global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
     // (the generator's working memory — the reset at the tail of the step — shares the octet's LDS: hs_k_reset.h GenScratch)
     __shared__ union PhysLds { OctRes R; GenScratch gen[kTile]; } lds;
     static_assert(sizeof(PhysLds) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
+#endif
     physics_step<ROUNDS>(S, lds.R, lds.gen);
 }
 
