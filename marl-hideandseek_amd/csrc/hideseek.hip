@@ -48,6 +48,7 @@ struct hs_sim {
     hipStream_t step_stream = nullptr;     // the stream of the open step
     bool blocking_own_stream = false;      // HS_STREAM=own: hs_step uses the handle's stream as hs_step_begin does
     int step_idx = 0;                      // physics launches mod 3 (SimState::tickSum)
+    int tile = 8;                          // worlds per physics wave: 8 (two waves per SIMD) or 4 (four waves per SIMD); HS_TILE
     // Load balancing between the physics waves (hs_k_balance.h; HS_BALANCE=0 turns it off, HS_BALANCE_PERIOD sets the steps between deals)
     bool balance = true;
     int balance_period = 32, steps_since_balance = 0;
@@ -128,9 +129,15 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     S.stepIdx = capture ? -1 : s->step_idx; if (!capture && !first && (stages & 1)) s->step_idx = (s->step_idx + 1) % 3;
     if (prof) HS_HIP(hipEventRecord(s->ev[0], strm));
     if (!first && (stages & 1)) {
-        // 17 body slots x 8 worlds need a third round of 64 lanes only with 6 agents per world
-        if (s->A > hs::kMaxAgents - 1) hipLaunchKernelGGL(hs::k_physics<3>, dim3(noct), dim3(hs::kPhysThreads), hs::kPhysDynLds, strm, S);
-        else hipLaunchKernelGGL(hs::k_physics<2>, dim3(noct), dim3(hs::kPhysThreads), hs::kPhysDynLds, strm, S);
+        // rounds of 64 lanes over the tile's bodies: 16 body slots per world with up to 5 agents, 17 with 6
+        const bool six = s->A > hs::kMaxAgents - 1;
+        if (s->tile == 8) {
+            if (six) hipLaunchKernelGGL((hs::k_physics<3, 8>), dim3(noct), dim3(hs::kPhysThreads), hs::kPhysDynLds, strm, S);
+            else hipLaunchKernelGGL((hs::k_physics<2, 8>), dim3(noct), dim3(hs::kPhysThreads), hs::kPhysDynLds, strm, S);
+        } else {
+            if (six) hipLaunchKernelGGL((hs::k_physics<2, 4>), dim3(2 * noct), dim3(hs::kPhysThreads), hs::kPhysDynLds / 2, strm, S);
+            else hipLaunchKernelGGL((hs::k_physics<1, 4>), dim3(2 * noct), dim3(hs::kPhysThreads), hs::kPhysDynLds / 2, strm, S);
+        }
     }
     if (prof) HS_HIP(hipEventRecord(s->ev[1], strm));
     // in a step the reset is the tail of k_physics; only Manager::init launches it on its own
@@ -159,7 +166,7 @@ int balance_worlds(hs_sim *s, hipStream_t strm) {
     const dim3 grid((nfull + 255) / 256), blk(256);
     hipLaunchKernelGGL(hs::k_balance_hist, grid, blk, 0, strm, S, nfull, s->bal_hist);
     hipLaunchKernelGGL(hs::k_balance_scan, dim3(1), dim3(hs::kBalanceBins), 0, strm, s->bal_hist, s->bal_cursor);
-    hipLaunchKernelGGL(hs::k_balance_deal, grid, blk, 0, strm, S, nfull, s->bal_cursor, s->bal_new_slot);
+    hipLaunchKernelGGL(hs::k_balance_deal, grid, blk, 0, strm, S, nfull, s->bal_cursor, s->bal_new_slot, s->tile);
     int rc;
     if ((rc = balance_move(s, strm, S.bpos, nfull)) != HS_OK || (rc = balance_move(s, strm, S.brot, nfull)) != HS_OK ||
         (rc = balance_move(s, strm, S.blin, nfull)) != HS_OK || (rc = balance_move(s, strm, S.bang, nfull)) != HS_OK ||
@@ -300,11 +307,11 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     // (every possible pair of every world: 92 KB per world, 1.5 GB at 16 000 worlds, of which a step touches a few MB)
     { char *p; HS_ALLOC(p, NP * hs::kAllDD * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, NP * hs::kAllSC * sizeof(hs::ManS)); S.wsSC = p; }
     HS_ALLOC(S.spPair, NP * (hs::kAllDD + hs::kAllSC)); HS_ALLOC(S.spInfo, NP * hs::kSpInfoWords);
-    HS_ALLOC(S.phaseTicks, 10 * (NP / hs::kTile) + 16 * 1024 + 16);     // + 1024 x 16 section counters of k_observe
+    HS_ALLOC(S.phaseTicks, hs::phase_ticks_obs_base((int)N) + 16 * 1024 + 16);     // + 1024 x 16 section counters of k_observe
     HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N); HS_ALLOC(S.wallHist, N);
     if ((rc = s->dalloc(&S.slotHdr, NP, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }      // world id -1: empty slot
     HS_ALLOC(S.lidarSinCos, 60);
-    HS_ALLOC(S.octTicks, NP / hs::kTile); HS_ALLOC(S.tickSum, 3);
+    HS_ALLOC(S.octTicks, NP / 4); HS_ALLOC(S.tickSum, 3);
     HS_ALLOC(s->bal_hist, hs::kBalanceBins); HS_ALLOC(s->bal_cursor, hs::kBalanceBins); HS_ALLOC(s->bal_new_slot, N);
     { char *tmp; s->bal_tmp_bytes = (size_t)S.walls.kRows * NP * sizeof(float); HS_ALLOC(tmp, s->bal_tmp_bytes); s->bal_tmp = tmp; }
     HS_ALLOC(S.status, 4);
@@ -326,6 +333,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     }
     if (const char *e = getenv("HS_GRAPH")) s->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HS_STREAM")) s->blocking_own_stream = std::strcmp(e, "own") == 0;
+    if (const char *e = getenv("HS_TILE")) { const int v = atoi(e); if (v == 4 || v == 8) s->tile = v; }
     if (const char *e = getenv("HS_BALANCE")) s->balance = atoi(e) != 0;
     if (const char *e = getenv("HS_BALANCE_PERIOD")) { const int v = atoi(e); if (v > 0) s->balance_period = v; }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -642,7 +650,7 @@ int32_t hs_xla_last_status(int32_t clear) { return clear ? g_xla_status.exchange
 int32_t hs_debug_phase_ticks(hs_sim *s, int64_t *out, int32_t max_groups) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    int nb = (s->S.N + hs::kTile - 1) / hs::kTile;          // one workgroup (wave) per octet
+    int nb = (s->S.N + hs::kTile - 1) / hs::kTile * (hs::kTile / s->tile);          // one workgroup (wave) per tile
     if (nb > max_groups) nb = max_groups;
     HS_HIP(hipMemcpy(out, s->S.phaseTicks, (size_t)nb * 10 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return nb;
@@ -653,7 +661,7 @@ int32_t hs_debug_observe_ticks(hs_sim *s, int64_t out[16]) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
     std::vector<int64_t> part(16 * 1024);
-    HS_HIP(hipMemcpy(part.data(), s->S.phaseTicks + (size_t)10 * ((s->S.N + hs::kTile - 1) / hs::kTile), part.size() * sizeof(int64_t),
+    HS_HIP(hipMemcpy(part.data(), s->S.phaseTicks + hs::phase_ticks_obs_base(s->S.N), part.size() * sizeof(int64_t),
                      hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; ++i) { out[i] = 0; for (int b = 0; b < 1024; ++b) out[i] += part[(size_t)b * 16 + i]; }
     return HS_OK;
@@ -662,7 +670,7 @@ int32_t hs_debug_observe_ticks(hs_sim *s, int64_t out[16]) {
 int32_t hs_debug_sat_counters(hs_sim *s, int64_t out[16]) {
     if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
     HS_HIP(hipSetDevice(s->cfg.gpu_id));
-    HS_HIP(hipMemcpy(out, s->S.phaseTicks + (size_t)10 * ((s->S.N + hs::kTile - 1) / hs::kTile) + 16 * 1024, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(out, s->S.phaseTicks + hs::phase_ticks_obs_base(s->S.N) + 16 * 1024, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return HS_OK;
 }
 

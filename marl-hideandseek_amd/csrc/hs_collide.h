@@ -286,16 +286,17 @@ HSD void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3 *c1, V3 *c2) {
 // [buffer][vertex][component][lane] so that the lanes of a wave hit different banks (a
 // per-lane struct of 48 words would be a 16-way bank conflict on every access).
 constexpr int kSatPairs = 32;           // pairs per round of the separating-axis search (two lanes per pair)
-constexpr int kClipLanes = 48;          // lanes of a wave that generate contacts in one round (each owns a column of the scratch)
-constexpr int kClipWords = 2 * 8 * 3 * kClipLanes;
-struct ClipBuf { float *base; int lane; };
+// lanes of a wave that generate contacts in one round (each owns a column of the scratch): 48 for a wave of 8 worlds, 24 for 4
+constexpr int clip_lanes(int tile) { return tile == 8 ? 48 : 24; }
+constexpr int clip_words(int lanes) { return 2 * 8 * 3 * lanes; }
+struct ClipBuf { float *base; int lane; int stride; };          // stride = clip lanes of the kernel (a compile-time constant at every use)
 HSD V3 cb_get(const ClipBuf &b, int w, int i) {
-    const float *p = b.base + ((w * 8 + i) * 3) * kClipLanes + b.lane;
-    return {p[0], p[kClipLanes], p[2 * kClipLanes]};
+    const float *p = b.base + ((w * 8 + i) * 3) * b.stride + b.lane;
+    return {p[0], p[b.stride], p[2 * b.stride]};
 }
 HSD void cb_set(const ClipBuf &b, int w, int i, V3 v) {
-    float *p = b.base + ((w * 8 + i) * 3) * kClipLanes + b.lane;
-    p[0] = v.x; p[kClipLanes] = v.y; p[2 * kClipLanes] = v.z;
+    float *p = b.base + ((w * 8 + i) * 3) * b.stride + b.lane;
+    p[0] = v.x; p[b.stride] = v.y; p[2 * b.stride] = v.z;
 }
 
 // Clip the incident face of I against the side planes of reference face fr of R; keep points on

@@ -38,13 +38,14 @@ __global__ void __launch_bounds__(kBalanceBins) k_balance_scan(int *hist, int *c
     hist[t] = 0;
 }
 // 3. rank of every world (order inside a class does not matter), its new slot; the load counters start over
-__global__ void __launch_bounds__(256) k_balance_deal(SimState S, int nfull, int *cursor, int *newSlot) {
+// (`tile`: worlds per physics wave, 8 or 4 — the groups the load is equalised over)
+__global__ void __launch_bounds__(256) k_balance_deal(SimState S, int nfull, int *cursor, int *newSlot, int tile) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nfull) return;
     const int r = atomicAdd(&cursor[load_class(S.loadAcc[w])], 1);
-    const int noct = nfull / kTile;
+    const int noct = nfull / tile;
     const int row = r / noct, col = r - row * noct;
-    newSlot[w] = ((row & 1) ? noct - 1 - col : col) * kTile + row;
+    newSlot[w] = ((row & 1) ? noct - 1 - col : col) * tile + row;
     S.loadAcc[w] = 0;
 }
 // 4. the rows of one column move from the old slot to the new one (out of place: src is a copy of the column)

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
     const int tid = threadIdx.x;
 #ifdef HS_PHASE_TIMING
     long long otk = wall_clock64();
-    long long *const oacc = S.phaseTicks + (size_t)10 * ((S.N + kTile - 1) / kTile) + (blockIdx.x & 1023) * 16;
+    long long *const oacc = S.phaseTicks + phase_ticks_obs_base(S.N) + (blockIdx.x & 1023) * 16;
 #define HS_OTICK(i) { const long long now_ = wall_clock64(); if ((tid & 63) == 0) atomicAdd((unsigned long long *)&oacc[i], (unsigned long long)(now_ - otk)); otk = now_; }
 #else
 #define HS_OTICK(i)

@@ -42,8 +42,9 @@ constexpr int kPhysDynLds = 20 * 1024;
 #else
 constexpr int kPhysDynLds = 0;
 #endif
-constexpr int kPhysWorlds = kTile;                 // worlds per workgroup
-constexpr int kMaxItems = kTile * (kMaxDDCand + kMaxSCand);        // convex-test items of an octet
+// The kernel exists for two tile sizes T (template parameter of the resident set and of every phase): T = 8, a wave per octet
+// of the tiled columns, two waves per SIMD (20 KiB of LDS, <= 256 registers) — and T = 4, a wave per half octet, four waves
+// per SIMD (10 KiB, 128 registers).  G = 64 / T lanes per world in the world-mapped phases.
 constexpr int kLdsWalls = 32;                      // walls per world staged in LDS for the broadphase (a world has
                                                    // 4..34; the rare ones beyond 32 are read from global memory)
 static_assert(kMaxSCand <= 32 && kMaxDDCand <= 16, "accepted-manifold masks are one word per world");
@@ -63,25 +64,32 @@ constexpr int kSpInfoWords = kNumDSlots + 1;      // S.spInfo per world: totals 
 // ---- the octet's resident working set (LDS) ----
 // Every column is [row][world of the octet] exactly like its block in HBM (hs_state.h Col), so loading and storing
 // are linear copies, and a wave whose lanes are (slot, world) or (world, slot) pairs touches 64 distinct banks.
-constexpr int kVelOffsetWords = 2 * 8 * 3 * 32;            // 6 KiB: beyond the manifold slots and the hull AABBs
-struct alignas(16) OctRes {
-    float pos[3][kNumDSlots][kTile];
-    float rot[4][kNumDSlots][kTile];        // w, x, y, z
-    float ppos[3][kNumDSlots][kTile];       // pose at the start of the substep
-    float prot[4][kNumDSlots][kTile];
-    int meta[kNumDSlots][kTile];            // meta_pack(); 0 = empty slot
+template <int T> struct alignas(16) OctResT {
+    static constexpr int kT = T;
+    static constexpr int kG = 64 / T;                                 // lanes per world
+    static constexpr int kClip = clip_lanes(T);                       // contact lanes per round
+    static constexpr int kClipWords = clip_words(kClip);
+    static constexpr int kSatPairs = kClip < hs::kSatPairs ? kClip : hs::kSatPairs;   // pairs per axis-search round (never more than a contact round can take)
+    static constexpr int kMaxItems = T * (kMaxDDCand + kMaxSCand);    // convex-test items of a tile
+    static constexpr int kSlots = kClip < 31 ? kClip : 31;            // manifold slots in the clip buffers (location 31 = global)
+    static constexpr int kVelOffsetWords = T == 8 ? 2 * 8 * 3 * 32 : 36 * 24;   // beyond the manifold slots and the hull AABBs
+    float pos[3][kNumDSlots][T];
+    float rot[4][kNumDSlots][T];        // w, x, y, z
+    float ppos[3][kNumDSlots][T];       // pose at the start of the substep
+    float prot[4][kNumDSlots][T];
+    int meta[kNumDSlots][T];            // meta_pack(); 0 = empty slot
     // Scratch of the broadphase / the convex tests.  The work list of the convex tests is written when the
     // broadphase loops are over (the walls are dead by then) and lies beyond the clip buffers that the convex
     // tests use, so both views can be live where they need to be.
     union {
         struct {
-            float lo[3][kNumDSlots][kTile], hi[3][kNumDSlots][kTile];   // hull AABBs: integrate -> detect
-            float wall[4][kLdsWalls][kTile];                            // cx, cy, hx, hy: staged by detect
+            float lo[3][kNumDSlots][T], hi[3][kNumDSlots][T];   // hull AABBs: integrate -> detect
+            float wall[4][kLdsWalls][T];                            // cx, cy, hx, hy: staged by detect
         } det;
         struct {
             float clip[kClipWords];                                     // polygon clipping of the convex tests
             unsigned short items[kMaxItems + 32];                       // world << 6 | candidate (32+ = static); ramp items start at a multiple of 32
-            int pend[4][kClipLanes];                                    // colliding pairs waiting for contact generation: item | axis code << 16, axis xyz
+            int pend[4][kClip];                                    // colliding pairs waiting for contact generation: item | axis code << 16, axis xyz
         } sat;
         // The velocities share the memory of the convex tests' scratch: between the integration of a substep (which consumes
         // them) and the derivation of the new ones from the pose change (after the position solve) the velocity of a DYNAMIC
@@ -93,30 +101,33 @@ struct alignas(16) OctRes {
         // The manifold slots (clip words 0 .. 31 * 36) lie below the velocities and stay valid through the solver phases.
         struct {
             float pad[kVelOffsetWords];
-            float lin[3][kNumDSlots][kTile];
-            float ang[3][kNumDSlots][kTile];
+            float lin[3][kNumDSlots][T];
+            float ang[3][kNumDSlots][T];
         } vel;
     } u;
-    unsigned short ddPair[kMaxDDCand][kTile];   // a | b << 5 | manifold location << 11 (pair_*() below)
-    unsigned short scPair[kMaxSCand][kTile];    // body | static << 5 | location << 11  (static = wall index, 36 + plane index)
-    unsigned short scInfo[kNumDSlots][kTile];   // per body: first static candidate | count << 8
-    unsigned int scAcc[kTile];                  // bit k: static candidate k of the world has a manifold (set by the convex test)
-    unsigned int ddAcc[kTile];                  // bit k: body-body candidate k has a manifold
-    unsigned int ddOrd[2][kTile];               // the accepted body-body candidates in solve order, 4 bits each (phase_dd)
-    float plane0[4][kTile];                     // the ground plane nx, ny, nz, d of every world
-    unsigned char bodies[kNumDSlots * kTile];   // compact list of existing bodies: slot << 3 | world
+    unsigned short ddPair[kMaxDDCand][T];   // a | b << 5 | manifold location << 11 (pair_*() below)
+    unsigned short scPair[kMaxSCand][T];    // body | static << 5 | location << 11  (static = wall index, 36 + plane index)
+    unsigned short scInfo[kNumDSlots][T];   // per body: first static candidate | count << 8
+    unsigned int scAcc[T];                  // bit k: static candidate k of the world has a manifold (set by the convex test)
+    unsigned int ddAcc[T];                  // bit k: body-body candidate k has a manifold
+    unsigned int ddOrd[2][T];               // the accepted body-body candidates in solve order, 4 bits each (phase_dd)
+    float plane0[4][T];                     // the ground plane nx, ny, nz, d of every world
+    unsigned char bodies[kNumDSlots * T];   // compact list of existing bodies: slot << 3 | world
     union {
-        unsigned char wallBodies[kNumDSlots * kTile];   // bodies with a wall / extra-plane manifold in this substep
-        unsigned char actGL[kMaxAgents][kTile];         // grab / lock requests (phase_pre only)
+        unsigned char wallBodies[kNumDSlots * T];   // bodies with a wall / extra-plane manifold in this substep
+        unsigned char actGL[kMaxAgents][T];         // grab / lock requests (phase_pre only)
     };
-    unsigned int wallSeen[kTile];               // bit s: body slot s had a wall / extra-plane manifold (previous step's while the
+    unsigned int wallSeen[T];               // bit s: body slot s had a wall / extra-plane manifold (previous step's while the
                                                 // body list is built, then this step's: SimState::wallHist)
-    unsigned char numWalls[kTile], numPlanes[kTile], ndd[kTile], nsc[kTile], seen[kTile], hasGrab[kTile];
-    unsigned char spill[kTile];                 // this substep: bit 0 body-body, bit 1 body-static candidates beyond the LDS capacity
-    int wid[kTile];                             // world id of each slot of the octet (SimState::worldOfSlot), -1 = empty slot
+    unsigned char numWalls[T], numPlanes[T], ndd[T], nsc[T], seen[T], hasGrab[T];
+    unsigned char spill[T];                 // this substep: bit 0 body-body, bit 1 body-static candidates beyond the LDS capacity
+    int wid[T];                             // world id of each slot of the octet (SimState::worldOfSlot), -1 = empty slot
 };
-static_assert(sizeof(OctRes) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
-static_assert(offsetof(OctRes, u.sat.items) >= offsetof(OctRes, u.det.wall), "items must not overlap the AABBs");
+static_assert(sizeof(OctResT<8>) <= 20 * 1024, "8 waves of 8 worlds share the CU's 160 KiB of LDS");
+static_assert(sizeof(OctResT<4>) <= 10 * 1024, "16 waves of 4 worlds share the CU's 160 KiB of LDS");
+static_assert(offsetof(OctResT<8>, u.sat.items) >= offsetof(OctResT<8>, u.det.wall) && offsetof(OctResT<4>, u.sat.items) >= offsetof(OctResT<4>, u.det.wall), "items must not overlap the AABBs");
+static_assert(sizeof(ManDD) / 4 * OctResT<8>::kSlots <= OctResT<8>::kVelOffsetWords && sizeof(ManDD) / 4 * OctResT<4>::kSlots <= OctResT<4>::kVelOffsetWords, "manifold slots lie below the velocities");
+static_assert(2 * 3 * kNumDSlots * 8 <= OctResT<8>::kVelOffsetWords && 2 * 3 * kNumDSlots * 4 <= OctResT<4>::kVelOffsetWords, "the hull AABBs lie below the velocities");
 
 // ---- candidate pairs and where their contact manifolds live ----
 // A manifold produced by the LAST contact-generation round of a substep (nearly always the only one) stays in LDS:
@@ -130,7 +141,7 @@ HSD int pair_b(int p) { return (p >> 5) & 63; }
 HSD int pair_loc(int p) { return (p >> 11) & 31; }
 HSD int pair_pack(int a, int b) { return a | (b << 5) | (kLocGlobal << 11); }
 static_assert(kNumDSlots <= 32 && kMaxWalls + kMaxPlanes <= 64, "pair encoding");
-static_assert(sizeof(ManDD) / 4 * kLocGlobal <= kClipWords && sizeof(ManDD) % 16 == 0 && sizeof(ManS) % 16 == 0, "manifold slots in the clip buffers");
+static_assert(sizeof(ManDD) % 16 == 0 && sizeof(ManS) % 16 == 0, "manifold records move 16 bytes at a time");
 constexpr int kManWords = sizeof(ManDD) / 4;          // slot stride (a ManS record uses the first 28 words)
 template <typename M> HSD void man_lds_load(const float *clip, int slot, M &m) {
     m = *reinterpret_cast<const M *>(clip + slot * kManWords);          // 16-byte reads
@@ -142,12 +153,12 @@ template <typename M> HSD void man_lds_set_lam(float *clip, int slot, int j, flo
 }
 
 // ---- accessors of the resident columns ----
-template <int C> HSD V3 rld3(const float (&a)[C][kNumDSlots][kTile], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g]}; }
-HSD Q rld4(const float (&a)[4][kNumDSlots][kTile], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g], a[3][slot][g]}; }
-HSD void rst3(float (&a)[3][kNumDSlots][kTile], int slot, int g, V3 v) { a[0][slot][g] = v.x; a[1][slot][g] = v.y; a[2][slot][g] = v.z; }
-HSD void rst4(float (&a)[4][kNumDSlots][kTile], int slot, int g, Q q) { a[0][slot][g] = q.w; a[1][slot][g] = q.x; a[2][slot][g] = q.y; a[3][slot][g] = q.z; }
+template <int C, int T> HSD V3 rld3(const float (&a)[C][kNumDSlots][T], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g]}; }
+template <int T> HSD Q rld4(const float (&a)[4][kNumDSlots][T], int slot, int g) { return {a[0][slot][g], a[1][slot][g], a[2][slot][g], a[3][slot][g]}; }
+template <int T> HSD void rst3(float (&a)[3][kNumDSlots][T], int slot, int g, V3 v) { a[0][slot][g] = v.x; a[1][slot][g] = v.y; a[2][slot][g] = v.z; }
+template <int T> HSD void rst4(float (&a)[4][kNumDSlots][T], int slot, int g, Q q) { a[0][slot][g] = q.w; a[1][slot][g] = q.x; a[2][slot][g] = q.y; a[3][slot][g] = q.z; }
 
-HSD void rbody_load(const OctRes &R, int g, int slot, BodyS &b) {
+template <class OR> HSD void rbody_load(const OR &R, int g, int slot, BodyS &b) {
     b.pos = rld3(R.pos, slot, g); b.rot = rld4(R.rot, slot, g);
     b.ppos = rld3(R.ppos, slot, g); b.prot = rld4(R.prot, slot, g);
     b.lin = rld3(R.u.vel.lin, slot, g); b.ang = rld3(R.u.vel.ang, slot, g);
@@ -157,8 +168,8 @@ HSD void rbody_load(const OctRes &R, int g, int slot, BodyS &b) {
     b.invI = dyn ? obj_inv_inertia(meta_obj(m)) : V3{0.f, 0.f, 0.f};
     body_refresh_inertia(b);
 }
-HSD void rbody_store_pose(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.pos, slot, g, b.pos); rst4(R.rot, slot, g, b.rot); }
-HSD void rbody_store_vel(OctRes &R, int g, int slot, const BodyS &b) { rst3(R.u.vel.lin, slot, g, b.lin); rst3(R.u.vel.ang, slot, g, b.ang); }
+template <class OR> HSD void rbody_store_pose(OR &R, int g, int slot, const BodyS &b) { rst3(R.pos, slot, g, b.pos); rst4(R.rot, slot, g, b.rot); }
+template <class OR> HSD void rbody_store_vel(OR &R, int g, int slot, const BodyS &b) { rst3(R.u.vel.lin, slot, g, b.lin); rst3(R.u.vel.ang, slot, g, b.ang); }
 HSD void derive_velocity(BodyS &b) {
     const float h = kSubstepH;
     b.lin = (b.pos - b.ppos) * (1.f / h);
@@ -176,19 +187,21 @@ HSD void mem_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 // Prefix sums and totals across lanes by DPP (one vector instruction per step) instead of shuffles through the LDS
 // crossbar (a round trip each, and the broadphase chains a dozen of them).
 template <int D> HSD int dpp_row_shr(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x110 + D, 0xF, 0xF, true); }   // lane i <- lane i - D of its row of 16, 0 beyond
-// inclusive prefix sum over the 8 lanes of a world (l = lane % 8): the steps' reach never leaves the group where it counts
-HSD int scan8_incl(int x, int l) {
+// inclusive prefix sum over the G = 8 or 16 lanes of a world (l = lane % G): the steps' reach never leaves the group where it counts
+template <int G> HSD int scanG_incl(int x, int l) {
     int y;
     y = dpp_row_shr<1>(x); if (l >= 1) x += y;
     y = dpp_row_shr<2>(x); if (l >= 2) x += y;
     y = dpp_row_shr<4>(x); if (l >= 4) x += y;
+    if (G == 16) { y = dpp_row_shr<8>(x); if (l >= 8) x += y; }
     return x;
 }
-// sum over the 8 lanes of a world, in every lane: pairs, quads (quad_perm), then the two quads of the half row (mirror)
-HSD int sum8_all(int x) {
+// sum over the G = 8 or 16 lanes of a world, in every lane: pairs, quads (quad_perm), then the two quads of the half row (mirror)
+template <int G> HSD int sumG_all(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
     x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
     x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);     // row_half_mirror
+    if (G == 16) x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);    // row_mirror: the other half row
     return x;
 }
 // inclusive prefix sum over the wave's 64 lanes
@@ -202,8 +215,8 @@ HSD int scan64_incl(int x) {
 // Geometry view of one world of the octet for trace_ray (hs_rays.h): bodies from the resident columns, walls and
 // the (at most 3) planes from global memory (the rays of the physics kernel — lock / grab, seeker -> hider line
 // of sight — are few; the lidar / visibility rays are k_observe's).
-struct ResGeom {
-    const OctRes &R; const SimState &S; int g; int w;
+template <class OR> struct ResGeom {
+    const OR &R; const SimState &S; int g; int w;
     HSD int g_meta(int i) const { return R.meta[i][g]; }
     HSD V3 g_pos(int i) const { return rld3(R.pos, i, g); }
     HSD Q g_rot(int i) const { return rld4(R.rot, i, g); }
@@ -227,31 +240,34 @@ struct BodyReg {
 };
 
 // ------------------------------------------------------------------------------------------
-// Linear copies between the octet's blocks of the tiled columns and LDS, 16 bytes per lane and trip (a block is
-// ROWS x 8 words: a multiple of 32 bytes, and so is its offset in the column and in OctRes).
-template <typename T, int ROWS>
-HSD void copy_in(T *dst, const Col<T, ROWS> &col, int o) {
-    static_assert(sizeof(T) == 4 && (ROWS * kTile) % 4 == 0, "16-byte pieces");
-    const float4 *src = reinterpret_cast<const float4 *>(col.octet(o));
+// Copies between the tile's part of the octet's blocks of the tiled columns and LDS, 16 bytes per lane and trip.  A block is
+// ROWS x 8 words; a tile of 8 takes whole rows (a linear copy), a tile of 4 the lower or upper half of every row.
+// p0 = the tile's first slot (a multiple of T).
+template <int T, typename E, int ROWS>
+HSD void copy_in(E *dst, const Col<E, ROWS> &col, int p0) {
+    static_assert(sizeof(E) == 4 && (T == 4 || T == 8), "16-byte pieces");
+    constexpr int PR = T / 4;                        // pieces per row
+    const float4 *src = reinterpret_cast<const float4 *>(col.octet(p0 >> 3)) + ((p0 & 7) >> 2);
     float4 *d = reinterpret_cast<float4 *>(dst);
-    for (int i = hs_lane(); i < ROWS * kTile / 4; i += 64) d[i] = src[i];
+    for (int i = hs_lane(); i < ROWS * PR; i += 64) d[i] = src[(i / PR) * 2 + i % PR];
 }
-template <typename T, int ROWS>
-HSD void copy_out(const Col<T, ROWS> &col, int o, const T *src) {
-    static_assert(sizeof(T) == 4 && (ROWS * kTile) % 4 == 0, "16-byte pieces");
-    float4 *dst = reinterpret_cast<float4 *>(col.octet(o));
+template <int T, typename E, int ROWS>
+HSD void copy_out(const Col<E, ROWS> &col, int p0, const E *src) {
+    static_assert(sizeof(E) == 4 && (T == 4 || T == 8), "16-byte pieces");
+    constexpr int PR = T / 4;
+    float4 *dst = reinterpret_cast<float4 *>(col.octet(p0 >> 3)) + ((p0 & 7) >> 2);
     const float4 *s = reinterpret_cast<const float4 *>(src);
-    for (int i = hs_lane(); i < ROWS * kTile / 4; i += 64) dst[i] = s[i];
+    for (int i = hs_lane(); i < ROWS * PR; i += 64) dst[(i / PR) * 2 + i % PR] = s[i];
 }
-
-// The velocity columns: only the rows of DYNAMIC bodies go back (OctRes::u.vel: the others were scratch during the step).
-template <typename OR>
-HSD void copy_out_vel(const Col<float, 3 * kNumDSlots> &col, int o, const float *src, const OR &R) {
-    float *dst = col.octet(o);
-    for (int i = hs_lane(); i < 3 * kNumDSlots * kTile; i += 64) {
-        const int slot = (i >> 3) % kNumDSlots, g = i & 7;
+// The velocity columns: only the rows of DYNAMIC bodies go back (OctResT::u.vel: the others were scratch during the step).
+template <class OR>
+HSD void copy_out_vel(const Col<float, 3 * kNumDSlots> &col, int p0, const float *src, const OR &R) {
+    constexpr int T = OR::kT;
+    float *dst = col.octet(p0 >> 3) + (p0 & 7);
+    for (int i = hs_lane(); i < 3 * kNumDSlots * T; i += 64) {
+        const int row = i / T, g = i % T, slot = row % kNumDSlots;
         const int m = R.meta[slot][g];
-        if (m != 0 && meta_resp(m) == RESP_DYNAMIC) dst[i] = src[i];
+        if (m != 0 && meta_resp(m) == RESP_DYNAMIC) dst[row * kTile + g] = src[i];
     }
 }
 
@@ -261,12 +277,12 @@ HSD void copy_out_vel(const Col<float, 3 * kNumDSlots> &col, int o, const float 
 // `aforce`: the octet's block of S.aforce (ExternalForce xyz + ExternalTorque z of the agents, written by phase_pre);
 // read here, four times per step by the agents' lanes, rather than kept in four registers for the whole step — the step
 // sits at its register budget.
-HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta, const float *aforce) {
+template <class OR> HSD void integrate_body(OR &R, BodyReg &b, int slot, int g, int meta, const float *aforce) {
     const int obj = meta_obj(meta);
     const bool dyn = meta_resp(meta) == RESP_DYNAMIC;
     V3 force = {0.f, 0.f, 0.f}; float torque = 0.f;
     if (dyn && slot >= kAgentSlot0) {
-        const float *f = aforce + (slot - kAgentSlot0) * kTile + g;
+        const float *f = aforce + (slot - kAgentSlot0) * kTile + g;          // (rows of the octet's block are 8 worlds wide whatever the tile)
         force = {f[0 * kMaxAgents * kTile], f[1 * kMaxAgents * kTile], f[2 * kMaxAgents * kTile]};
         torque = f[3 * kMaxAgents * kTile];
     }
@@ -309,20 +325,22 @@ HSD void integrate_body(OctRes &R, BodyReg &b, int slot, int g, int meta, const 
 // box-only items in .x and of items that involve a ramp (wedge hull) in .y; the ramp items start at the next
 // multiple of 32 so that most rounds of the convex test run the box code only.
 struct ItemCounts { int nbox, nwedge; bool anySpill; };
-template <int JB>            // body slots per lane: 2 covers 16 slots (<= 5 agents), 3 all 17
-HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
-    constexpr int G = 8;
+template <int JB, class OR>   // JB body slots per lane: with 8 lanes per world 2 cover 16 slots (<= 5 agents), 3 all 17; with 16 lanes 1 / 2
+HSD ItemCounts phase_detect(const SimState &S, OR &R, int NS) {
+    constexpr int T = OR::kT, G = OR::kG;
     const int L = hs_lane(), g = L / G, l = L % G;
-    const int o = blockIdx.x;
-    // the octet's walls -> LDS, 16 bytes per lane and component (rows beyond a world's count are never read)
+    // the tile's walls -> LDS, 16 bytes per lane and component (rows beyond a world's count are never read)
     {
-        static_assert(kLdsWalls * kTile == 4 * 64, "one float4 per lane per component");
-        const float *src = S.walls.octet(o);
+        constexpr int PR = T / 4;                                   // 16-byte pieces per row of the tile
+        static_assert(kLdsWalls * PR <= 64, "one piece per lane per component");
+        const float *src = S.walls.octet(S.wbeg >> 3) + (S.wbeg & 7);
         float4 v[4];
+        const bool on = L < kLdsWalls * PR;
+        const int row = L / PR, part = L % PR;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = *(const float4 *)(src + c * (kMaxWalls * kTile) + 4 * L);
+        for (int c = 0; c < 4; ++c) if (on) v[c] = *(const float4 *)(src + (c * kMaxWalls + row) * kTile + 4 * part);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *(float4 *)(&R.u.det.wall[c][0][0] + 4 * L) = v[c];
+        for (int c = 0; c < 4; ++c) if (on) *(float4 *)(&R.u.det.wall[c][row][4 * part]) = v[c];
     }
     if (l == 0) { R.scAcc[g] = 0u; R.ddAcc[g] = 0u; }
     wave_sync();
@@ -380,9 +398,9 @@ HSD ItemCounts phase_detect(const SimState &S, OctRes &R, int NS) {
     for (int jb = 0; jb < JB; ++jb) {
         if (dynamic[jb]) for (int p = 1; p < npl; ++p) s_mask[jb] |= 1ull << (kMaxWalls + p);
         const int cdd = __popc(dd_mask[jb]), csc = __popcll(s_mask[jb]);
-        const int in_dd = scan8_incl(cdd, l), in_sc = scan8_incl(csc, l);
+        const int in_dd = scanG_incl<G>(cdd, l), in_sc = scanG_incl<G>(csc, l);
         bdd[jb] = tot_dd + in_dd - cdd; bsc[jb] = tot_sc + in_sc - csc;
-        tot_dd += sum8_all(cdd); tot_sc += sum8_all(csc);
+        tot_dd += sumG_all<G>(cdd); tot_sc += sumG_all<G>(csc);
         add[jb] = cdd ? max(0, min(cdd, kMaxDDCand - bdd[jb])) : 0;
         asc[jb] = csc ? max(0, min(csc, kMaxSCand - bsc[jb])) : 0;
         tot_items += add[jb] + asc[jb];
@@ -473,14 +491,14 @@ HSD SpillCtx spill_ctx(const SimState &S) { return {S.walls.p, S.planes.p, (ManD
 // Convex tests of the spilled pairs: world by world, body-body then body-static, 32 pairs per trip, two lanes per pair
 // for the axis search (sat_axes) and the pair's first lane for the contact generation right away (no compaction: this
 // is the rare path).  Every spilled pair gets a record at its place of the workspace; np = 0 says "no manifold".
-HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
-    OctRes &R = *Rp;
+template <class OR> HS_COLD void spill_sat(SpillCtx c, OR *Rp) {
+    OR &R = *Rp;
     const int lane = hs_lane() & 63;
     const bool hi = (lane & 1) != 0;
     const Col<float, 4 * kMaxWalls> walls = {const_cast<float *>(c.walls)};
     const Col<float, 4 * kMaxPlanes> planes = {const_cast<float *>(c.planes)};
 #pragma unroll 1
-    for (int g = 0; g < kTile; ++g) {
+    for (int g = 0; g < OR::kT; ++g) {
         const int fl = __builtin_amdgcn_readfirstlane((int)R.spill[g]);
         if (fl == 0) continue;
         const int w = c.wbeg + g;
@@ -491,9 +509,9 @@ HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
             const bool isdd = kind == 0;
             const int n = isdd ? tot & 0xffff : tot >> 16;
 #pragma unroll 1
-            for (int base = isdd ? kMaxDDCand : kMaxSCand; base < n; base += kSatPairs) {
+            for (int base = isdd ? kMaxDDCand : kMaxSCand; base < n; base += OR::kSatPairs) {
                 const int kk = base + (lane >> 1);
-                if (kk < n) {
+                if (kk < n && (lane >> 1) < OR::kSatPairs) {
                     const int pair = c.spPair[(size_t)w * (kAllDD + kAllSC) + (isdd ? 0 : kAllDD) + kk];
                     const int a = pair_a(pair), bsel = pair_b(pair);
                     const int oa = meta_obj(R.meta[a][g]);
@@ -515,7 +533,7 @@ HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
                                                 : hull_src_wall(walls(0 * kMaxWalls + bsel, w), walls(1 * kMaxWalls + bsel, w),
                                                                 walls(2 * kMaxWalls + bsel, w), walls(3 * kMaxWalls + bsel, w));
                         const AxisResult res = sat_axes(ha, hb, hi);
-                        const ClipBuf cb = {R.u.sat.clip, lane >> 1};
+                        const ClipBuf cb = {R.u.sat.clip, lane >> 1, OR::kClip};
                         if (!hi && res.code != 0 && !sat_contact(ha, hb, res, cb, raw)) raw.np = 0;
                     }
                     if (!hi) {
@@ -557,11 +575,11 @@ HS_COLD void spill_sat(SpillCtx c, OctRes *Rp) {
 // (World by world in a wave-uniform loop, here and below: the addresses into the large per-world workspaces are then
 // scalar arithmetic.  Per-lane 64-bit pointers would be hoisted to the top of the kernel as loop invariants and
 // spilled to scratch memory there — the step's hot path sits exactly at the 256-register budget of two waves per SIMD.)
-template <bool POS>
-HS_COLD void spill_dd(SpillCtx c, OctRes *Rp) {
-    OctRes &R = *Rp;
+template <bool POS, class OR>
+HS_COLD void spill_dd(SpillCtx c, OR *Rp) {
+    OR &R = *Rp;
 #pragma unroll 1
-    for (int g = 0; g < kTile; ++g) {
+    for (int g = 0; g < OR::kT; ++g) {
         if ((__builtin_amdgcn_readfirstlane((int)R.spill[g]) & 1) == 0) continue;
         const int w = c.wbeg + g;
         const int nall = __builtin_amdgcn_readfirstlane(c.spInfo[(size_t)w * kSpInfoWords]) & 0xffff;
@@ -592,11 +610,11 @@ HS_COLD void spill_dd(SpillCtx c, OctRes *Rp) {
 
 // The spilled static manifolds: a lane per body of the world walks the body's in order, after the body's ground manifold
 // and its static manifolds of the fast path — the oracle's order per body.
-template <bool POS>
-HS_COLD void spill_static(SpillCtx c, OctRes *Rp, int NS) {
-    OctRes &R = *Rp;
+template <bool POS, class OR>
+HS_COLD void spill_static(SpillCtx c, OR *Rp, int NS) {
+    OR &R = *Rp;
 #pragma unroll 1
-    for (int g = 0; g < kTile; ++g) {
+    for (int g = 0; g < OR::kT; ++g) {
         if ((__builtin_amdgcn_readfirstlane((int)R.spill[g]) & 2) == 0) continue;
         const int w = c.wbeg + g;
         const int slot = hs_lane();
@@ -649,8 +667,8 @@ HS_COLD void spill_static(SpillCtx c, OctRes *Rp, int NS) {
 // octet's candidate pairs, two lanes per pair (2k and 2k + 1), 32 pairs per round; the pairs that collide are appended
 // to a pending list.  Stage 2 — contact generation, the long part: polygon clipping on one lane — runs on the pending
 // pairs only, compacted, 32 per round: about a third of the candidates collide, so one round serves the whole octet.
-HSD HullSrc sat_hull_a(const OctRes &R, int g, int a) { return hull_src_body(meta_obj(R.meta[a][g]), rld3(R.pos, a, g), rld4(R.rot, a, g)); }
-HSD HullSrc sat_hull_b(const SimState &S, const OctRes &R, int g, int w, bool isdd, int bsel) {
+template <class OR> HSD HullSrc sat_hull_a(const OR &R, int g, int a) { return hull_src_body(meta_obj(R.meta[a][g]), rld3(R.pos, a, g), rld4(R.rot, a, g)); }
+template <class OR> HSD HullSrc sat_hull_b(const SimState &S, const OR &R, int g, int w, bool isdd, int bsel) {
     if (isdd) return hull_src_body(meta_obj(R.meta[bsel][g]), rld3(R.pos, bsel, g), rld4(R.rot, bsel, g));
     // (the staged walls share their LDS with the clip buffers: from global memory here)
     return hull_src_wall(S.walls(0 * kMaxWalls + bsel, w), S.walls(1 * kMaxWalls + bsel, w),
@@ -658,9 +676,9 @@ HSD HullSrc sat_hull_b(const SimState &S, const OctRes &R, int g, int w, bool is
 }
 // stage 2 for the first `npend` pending pairs: lane i < 32 takes pair i.  `last`: this is the substep's last round,
 // whose manifolds stay in LDS (in the lane's own clip column); returns whether a manifold went to global memory.
-HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PARAMS) {
+template <class OR> HSD bool sat_flush(const SimState &S, OR &R, int npend, bool last HS_TICK_PARAMS) {
     const int lane = hs_lane() & 63;
-    const bool toLds = last && lane < kLocGlobal;
+    const bool toLds = last && lane < OR::kSlots;
     bool wroteGlobal = false;
     int mw[kManWords]; int mkind = 0, mkk = 0, mg = 0, mpair = 0;      // the manifold for LDS: 1 body-body, 2 body-static
     if (lane < npend) {
@@ -674,7 +692,7 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PA
         const int kk = idx & 31;
         const int pair = isdd ? R.ddPair[kk][g] : R.scPair[kk][g];
         const int a = pair_a(pair), bsel = pair_b(pair);
-        const ClipBuf cb = {R.u.sat.clip, lane};
+        const ClipBuf cb = {R.u.sat.clip, lane, OR::kClip};
         RawManifold raw;
         const bool plane = res.code == 3;                 // an extra plane of a debug level (static candidate kMaxWalls + p)
         bool have;
@@ -744,8 +762,8 @@ HSD bool sat_flush(const SimState &S, OctRes &R, int npend, bool last HS_TICK_PA
 }
 // Returns whether any manifold of the substep lies in the global workspace (wave-uniform): only then do the solver
 // phases have to wait for global memory at all.
-template <bool SPILL>
-HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
+template <bool SPILL, class OR>
+HSD bool phase_sat(const SimState &S, OR &R, ItemCounts ic HS_TICK_PARAMS) {
     const int wedge0 = (ic.nbox + 31) / 32 * 32;
     const int lane = hs_lane() & 63;
     const bool hi = (lane & 1) != 0;                  // the second lane of a pair (box rounds: lanes 2k, 2k + 1)
@@ -760,12 +778,12 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
 #endif
     // rounds over the box-only items, 2 lanes per pair and 32 pairs per round, then over the items with a wedge, 16 lanes
     // per pair and 4 pairs per round (sat_axes_wide); `lead`: the lane of a pair that files its result
-    const int boxRounds = (ic.nbox + kSatPairs - 1) / kSatPairs, wedgeRounds = (ic.nwedge + 3) / 4;
+    const int boxRounds = (ic.nbox + OR::kSatPairs - 1) / OR::kSatPairs, wedgeRounds = (ic.nwedge + 3) / 4;
     // (pairs beyond the LDS capacities, if any world of the octet has them: tested and turned into manifolds first, while
     // the clip buffers are free)
     if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_sat(spill_ctx(S), &R); usedGlobal = true; }
     // The axis-search rounds and the contact rounds alternate as two plain loops — as many axis-search rounds as the pending
-    // list (kClipLanes entries) is sure to hold, then one contact round — instead of a contact round nested inside the
+    // list (OR::kClip entries) is sure to hold, then one contact round — instead of a contact round nested inside the
     // axis-search loop: the two bodies never share registers.  (A round files at most as many pairs as it has items.)
     const int totalRounds = boxRounds + wedgeRounds;
     int round = 0;
@@ -774,15 +792,15 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
         HS_SAT_T(const long long tr0_ = wall_clock64();)
         const bool wide = round >= boxRounds;
         {
-            const int itemsHere = wide ? min(4, wedge0 + ic.nwedge - (wedge0 + (round - boxRounds) * 4)) : min(kSatPairs, ic.nbox - round * kSatPairs);
-            if (npend + itemsHere > kClipLanes) break;            // (the pending list goes through a contact round first)
+            const int itemsHere = wide ? min(4, wedge0 + ic.nwedge - (wedge0 + (round - boxRounds) * 4)) : min(OR::kSatPairs, ic.nbox - round * OR::kSatPairs);
+            if (npend + itemsHere > OR::kClip) break;            // (the pending list goes through a contact round first)
         }
-        const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * kSatPairs;
+        const int base = wide ? wedge0 + (round - boxRounds) * 4 : round * OR::kSatPairs;
         const int it = wide ? base + (lane >> 4) : base + (lane >> 1);
         const bool lead = wide ? (lane & 15) == 0 : !hi;
         AxisResult res = {0, {0.f, 0.f, 0.f}};
         int item = 0;
-        if (wide ? it < wedge0 + ic.nwedge : it < ic.nbox) {
+        if (wide ? it < wedge0 + ic.nwedge : (it < ic.nbox && (lane >> 1) < OR::kSatPairs)) {
             item = R.u.sat.items[it];
             const int g = item >> 6, idx = item & 63;
             const int w = S.wbeg + g;
@@ -822,7 +840,7 @@ HSD bool phase_sat(const SimState &S, OctRes &R, ItemCounts ic HS_TICK_PARAMS) {
     if (usedGlobal) mem_sync();          // the manifolds in global memory are complete for the lanes that solve them
 #ifdef HS_SAT_COUNTERS
     if (lane == 0) {      // work counters of the convex tests (tools/phase_timing.py; their atomics disturb the phase times)
-        unsigned long long *c = (unsigned long long *)S.phaseTicks + (size_t)10 * gridDim.x + 16 * 1024;
+        unsigned long long *c = (unsigned long long *)S.phaseTicks + phase_ticks_obs_base(S.N) + 16 * 1024;
         atomicAdd(&c[0], 1ull); atomicAdd(&c[1], (unsigned long long)ic.nbox); atomicAdd(&c[2], (unsigned long long)ic.nwedge);
         atomicAdd(&c[3], (unsigned long long)(boxRounds + wedgeRounds)); atomicAdd(&c[4], (unsigned long long)nhit_total);
         atomicAdd(&c[5], (unsigned long long)nflush);
@@ -959,11 +977,11 @@ HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float
     else { me.lin = me.lin - p * me.invM; me.ang = me.ang - da; }
 }
 
-template <bool POS, bool SPILL>
-HSD void phase_dd(const SimState &S, OctRes &R, bool anySpill) {
-    constexpr int GL = 8, PAIRS = GL / 2;
+template <bool POS, bool SPILL, class OR>
+HSD void phase_dd(const SimState &S, OR &R, bool anySpill) {
+    constexpr int GL = OR::kG, PAIRS = GL / 2;                    // lanes per world (8 or 16); manifolds of a world in flight at once
     const int L = hs_lane(), g = L / GL, q = L % GL;
-    const int h = q >> 1;                                         // this lane's pair within the world's 8 lanes
+    const int h = q >> 1;                                         // this lane's pair within the world's lanes
     const bool isA = (q & 1) == 0;
     const int gbit0 = g * GL;                                     // first lane of this group in the wave
     const int w = S.wbeg + g;                                     // the world's slot in the tiled columns
@@ -1034,8 +1052,10 @@ HSD void phase_dd(const SimState &S, OctRes &R, bool anySpill) {
             const unsigned long long pend_mask = __ballot(pending && isA);
             if (pend_mask == 0ull) break;
             // (bit 2p of the world's 8 bits: pair p is pending)
-            const unsigned wp = (unsigned)(pend_mask >> gbit0) & 0x55u;
-            const unsigned pendPairs = (wp & 1u) | ((wp >> 1) & 2u) | ((wp >> 2) & 4u) | ((wp >> 3) & 8u);
+            const unsigned wp = (unsigned)(pend_mask >> gbit0);
+            unsigned pendPairs = 0u;
+#pragma unroll
+            for (int p = 0; p < PAIRS; ++p) pendPairs |= ((wp >> (2 * p)) & 1u) << p;
 #ifdef HS_DD_ONE_LANE
             if (pending && (dep & pendPairs) == 0u) {
                 if (isA) {
@@ -1091,8 +1111,8 @@ HSD void phase_dd(const SimState &S, OctRes &R, bool anySpill) {
 // round wait, so their wall manifolds are solved in a round of their own — one lane per such body, compacted over
 // the octet (wallBodies) — between the ground pass and the velocity derivation.
 struct WallLists { int nwb, nEarly; };     // listed bodies; how many of them belong to a round before the last one
-template <int ROUNDS>
-HSD WallLists list_wall_bodies(OctRes &R, int nbodies, int lastRound) {
+template <int ROUNDS, class OR>
+HSD WallLists list_wall_bodies(OR &R, int nbodies, int lastRound) {
     const int L = hs_lane();
     int n = 0, nEarly = 0;
 #pragma unroll
@@ -1110,7 +1130,7 @@ HSD WallLists list_wall_bodies(OctRes &R, int nbodies, int lastRound) {
     return {n, nEarly};
 }
 
-HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
+template <class OR> HSD void ground_pos(OR &R, BodyReg &b, int slot, int g, int meta) {
     if (meta_resp(meta) != RESP_DYNAMIC || b.np == 0) return;
     const int obj = meta_obj(meta);
     BodyS me;
@@ -1128,7 +1148,7 @@ HSD void ground_pos(OctRes &R, BodyReg &b, int slot, int g, int meta) {
                                                               yaw, dj[j], share);
     rbody_store_pose(R, g, slot, me);
 }
-HSD void ground_vel(OctRes &R, const BodyReg &b, int slot, int g, int meta) {
+template <class OR> HSD void ground_vel(OR &R, const BodyReg &b, int slot, int g, int meta) {
     if (meta_resp(meta) != RESP_DYNAMIC || b.np == 0) return;
     const int obj = meta_obj(meta);
     BodyS me, none;
@@ -1142,8 +1162,8 @@ HSD void ground_vel(OctRes &R, const BodyReg &b, int slot, int g, int meta) {
     rbody_store_vel(R, g, slot, me);
 }
 // The wall / extra-plane manifolds of the listed bodies, one lane per body, candidates in solve order.
-template <bool POS>
-HSD void wall_round(const SimState &S, OctRes &R, int first, int nwb) {
+template <bool POS, class OR>
+HSD void wall_round(const SimState &S, OR &R, int first, int nwb) {
     for (int i = first + hs_lane(); i < nwb; i += 64) {
         const int t = R.wallBodies[i];
         const int slot = t >> 3, g = t & 7;
@@ -1188,8 +1208,8 @@ HSD void wall_round(const SimState &S, OctRes &R, int first, int nwb) {
 // static manifolds — the ground manifold from its registers, or a listed body's accepted candidates from LDS — through
 // one and the same solve code.  What does not fit (bodies of the last round itself, more listed bodies than idle lanes)
 // is left to wall_round.  Per body the order stays ground, then its static candidates by index.
-template <bool POS>
-HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int slot, int g, int meta, int nLast, int nMerged) {
+template <bool POS, class OR>
+HSD void last_round(const SimState &S, OR &R, BodyReg &b, bool valid, int slot, int g, int meta, int nLast, int nMerged) {
     const int mi = (int)hs_lane() - nLast;
     const bool walls = mi >= 0 && mi < nMerged;
     unsigned todo = 0u; int bsc = 0;
@@ -1247,7 +1267,7 @@ HSD void last_round(const SimState &S, OctRes &R, BodyReg &b, bool valid, int sl
     }
     if (POS) rbody_store_pose(R, g, slot, me); else rbody_store_vel(R, g, slot, me);
 }
-HSD void derive_body_velocity(OctRes &R, int slot, int g, int meta) {
+template <class OR> HSD void derive_body_velocity(OR &R, int slot, int g, int meta) {
     if (meta_resp(meta) != RESP_DYNAMIC) return;
     BodyS me;
     me.pos = rld3(R.pos, slot, g); me.rot = rld4(R.rot, slot, g);
@@ -1260,9 +1280,9 @@ HSD void derive_body_velocity(OctRes &R, int slot, int g, int meta) {
 // actionSystem (sim.cpp:270-370) for one world, agents in interface order, run by ONE lane: lock / grab ray casts
 // against the resident geometry, joint create / destroy.  Meta words change in LDS (copied back at the end of
 // the launch); the joint table lives in global memory.
-HSD void action_system(const SimState &S, OctRes &R, int g, int A_, int teams) {
+template <class OR> HSD void action_system(const SimState &S, OR &R, int g, int A_, int teams) {
     const int w = S.wbeg + g;
-    const ResGeom geom = {R, S, g, w};
+    const ResGeom<OR> geom = {R, S, g, w};
     for (int i = 0; i < A_; ++i) {
         const int fl = R.actGL[i][g];
         if (fl == 0) continue;
@@ -1314,12 +1334,13 @@ HSD void action_system(const SimState &S, OctRes &R, int g, int A_, int teams) {
 // Before the substeps: movementSystem | instantMovementSystem (sim.cpp:202-254) and actionSystem (:270-370).
 // A lane per (agent, world) maps the action row to a force; a lane per world then runs the action system for the
 // worlds in which an agent locks or grabs (scripts/benchmark.py never does, scripts/jax_train.py does all the time).
-HSD void phase_pre(const SimState &S, OctRes &R) {
+template <class OR> HSD void phase_pre(const SimState &S, OR &R) {
+    constexpr int T = OR::kT;
     const int A_ = S.A, L = hs_lane();
     const bool instant = (S.flags & FLAG_ZERO_AGENT_VELOCITY) == FLAG_ZERO_AGENT_VELOCITY;
     bool need_action = false;
-    if (L < kMaxAgents * kTile) {
-        const int agent = L / kTile, g = L % kTile;
+    if (L < kMaxAgents * T) {
+        const int agent = L / T, g = L % T;
         const int w = R.wid[g], p = S.wbeg + g;          // world id (exports, per-world scalars) / slot (columns)
         int fl = 0;
         if (agent < A_ && w >= 0) {
@@ -1344,13 +1365,13 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
     }
     const bool any = __ballot(need_action) != 0ull;
     wave_sync();                          // actGL and the forces (global memory) are in place
-    if (any && L < kTile && R.wid[L] >= 0) {   // one lane per world: the ray casts of a world are sequential
+    if (any && L < T && R.wid[L] >= 0) {   // one lane per world: the ray casts of a world are sequential
         bool want = false;
         for (int a = 0; a < A_; ++a) want |= R.actGL[a][L] != 0;
         if (want) action_system(S, R, L, A_, S.teams[R.wid[L]]);
     }
     // worlds with a grab joint take part in the body-body phase of every substep
-    if (L < kTile) {
+    if (L < T) {
         bool grab = false;
         if (R.wid[L] >= 0) for (int a = 0; a < kMaxAgents; ++a) grab |= S.grabOther(a, S.wbeg + L) >= 0;
         R.hasGrab[L] = grab ? 1 : 0;
@@ -1360,8 +1381,8 @@ HSD void phase_pre(const SimState &S, OctRes &R) {
 
 // After the substeps: agentZeroVelSystem (sim.cpp:258-268), rewardsVisSystem (:763-804),
 // outputRewardsDonesSystem (:806-841), updateEpisodeResultsSystem (:843-893).  8 lanes per world.
-HSD void phase_post(const SimState &S, OctRes &R) {
-    constexpr int G = 8;
+template <class OR> HSD void phase_post(const SimState &S, OR &R) {
+    constexpr int G = OR::kG;
     const int L = hs_lane(), g = L / G, l = L % G;
     const int w = R.wid[g], p = S.wbeg + g;          // world id (exports, per-world scalars) / slot (columns)
     const int A_ = S.A;
@@ -1384,7 +1405,7 @@ HSD void phase_post(const SimState &S, OctRes &R) {
     for (int pr = l; wok && step >= kNumPrepSteps - 1 && pr < 9; pr += G) {      // (seeker, hider) pairs
         const int si = pr / 3, hi_ = pr % 3;
         if (si < cnt_seekers(counts) && hi_ < cnt_hiders(counts)) {
-            const ResGeom geom = {R, S, g, p};
+            const ResGeom<OR> geom = {R, S, g, p};
             const int ss = kAgentSlot0 + team_seeker(teams, si), hs_ = kAgentSlot0 + team_hider(teams, hi_);
             const V3 spos = geom.g_pos(ss);
             const V3 fwd = qrot(geom.g_rot(ss), {0.f, 1.f, 0.f});
@@ -1436,8 +1457,8 @@ HSD void phase_post(const SimState &S, OctRes &R) {
 // ------------------------------------------------------------------------------------------
 // The static-contact passes of a substep: ground_pos / ground_vel for the rounds before LASTR, then last_round for round
 // LASTR (the last round that holds bodies) with the wall manifolds of earlier rounds' bodies in its idle lanes.
-template <int ROUNDS, int LASTR, bool POS>
-HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int nLast, int nMerged) {
+template <int ROUNDS, int LASTR, bool POS, class OR>
+HSD void static_passes(const SimState &S, OR &R, BodyReg (&br)[ROUNDS], int nbodies, int nLast, int nMerged) {
     const int L = hs_lane();
 #pragma unroll
     for (int r = 0; r < LASTR; ++r) {
@@ -1458,8 +1479,8 @@ HSD void static_passes(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int 
 // velocities from the pose change -> body-body and static velocity passes (-> integration for the next substep).
 #define HS_BODY(r) const bool valid = (r) * 64 + L < nbodies; const int t_ = valid ? R.bodies[(r) * 64 + L] : 0; \
                    const int slot = t_ >> 3, g = t_ & 7; const int meta = valid ? R.meta[slot][g] : 0;
-template <int ROUNDS, bool SPILL>
-HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int nbodies, int NS, ItemCounts ic, bool integrateNext,
+template <int ROUNDS, bool SPILL, class OR>
+HSD void substep_rest(const SimState &S, OR &R, BodyReg (&br)[ROUNDS], int nbodies, int NS, ItemCounts ic, bool integrateNext,
                       const float *aforce HS_TICK_PARAMS) {
     const int L = hs_lane();
     const bool manGlobal = phase_sat<SPILL>(S, R, ic HS_TICK_ARGS);
@@ -1468,12 +1489,14 @@ HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int n
     HS_CTICK(4, 6)
     // (with 6 agents a third round exists for up to 136 bodies, but an octet rarely holds more than 128: then round 1 is
     // the last one that holds bodies, and the passes are two, not three)
-    const bool shortLast = ROUNDS == 3 && nbodies <= 128;
-    const int lastRound = shortLast ? 1 : ROUNDS - 1;
+    // (likewise the second round of a 4-world wave with 6 agents: 68 bodies at most, rarely more than 64)
+    constexpr int kShortLastR = ROUNDS >= 2 ? ROUNDS - 2 : 0;
+    const bool shortLast = (ROUNDS == 3 || (ROUNDS == 2 && OR::kT == 4)) && nbodies <= 64 * (ROUNDS - 1);
+    const int lastRound = shortLast ? kShortLastR : ROUNDS - 1;
     const WallLists wl = list_wall_bodies<ROUNDS>(R, nbodies, lastRound);
     const int nLast = max(nbodies - 64 * lastRound, 0);            // bodies of the last round
     const int nMerged = min(wl.nEarly, 64 - nLast);                 // listed bodies its idle lanes take
-    if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), true>(S, R, br, nbodies, nLast, nMerged);
+    if (shortLast) static_passes<ROUNDS, kShortLastR, true>(S, R, br, nbodies, nLast, nMerged);
     else static_passes<ROUNDS, ROUNDS - 1, true>(S, R, br, nbodies, nLast, nMerged);
     if (wl.nwb > nMerged) { wall_round<true>(S, R, nMerged, wl.nwb); wave_sync(); }
     if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_static<true>(spill_ctx(S), &R, NS); wave_sync(); }
@@ -1483,7 +1506,7 @@ HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int n
     HS_CTICK(5, 7)
     phase_dd<false, SPILL>(S, R, ic.anySpill);
     HS_CTICK(6, 8)
-    if (shortLast) static_passes<ROUNDS, (ROUNDS == 3 ? 1 : ROUNDS - 1), false>(S, R, br, nbodies, nLast, nMerged);
+    if (shortLast) static_passes<ROUNDS, kShortLastR, false>(S, R, br, nbodies, nLast, nMerged);
     else static_passes<ROUNDS, ROUNDS - 1, false>(S, R, br, nbodies, nLast, nMerged);
     if (wl.nwb > nMerged) { wall_round<false>(S, R, nMerged, wl.nwb); wave_sync(); }
     if (SPILL && __builtin_expect(ic.anySpill, 0)) { spill_static<false>(spill_ctx(S), &R, NS); wave_sync(); }
@@ -1497,10 +1520,12 @@ HSD void substep_rest(const SimState &S, OctRes &R, BodyReg (&br)[ROUNDS], int n
 
 // ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
 // 6 agents (17 slots x 8 worlds = 136 bodies at most).
-template <int ROUNDS>
-HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
-    const int L = hs_lane(), o = blockIdx.x;
-    S.wbeg = o * kTile;                               // first slot of the octet in the tiled columns
+template <int ROUNDS, class OR>
+HSD void physics_step(SimState &S, OR &R, GenScratch *gen) {
+    constexpr int T = OR::kT;
+    const int L = hs_lane(), o = blockIdx.x;            // o: this wave's tile
+    S.wbeg = o * T;                                   // first slot of the tile in the tiled columns
+    const int p0 = S.wbeg;
     const int NS = kAgentSlot0 + S.A;                 // body slots in use
     const int noct = gridDim.x;
     // The launch ends with its slowest wave: the physics waves that were slow in the previous step (the same worlds:
@@ -1526,10 +1551,10 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     long long tk = wall_clock64(); long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // ---- the octet's columns -> LDS (the blocks are contiguous; worlds beyond N are zero padding = empty slots)
-    copy_in(&R.pos[0][0][0], S.bpos, o); copy_in(&R.rot[0][0][0], S.brot, o);
-    copy_in(&R.u.vel.lin[0][0][0], S.blin, o); copy_in(&R.u.vel.ang[0][0][0], S.bang, o);
-    copy_in(&R.meta[0][0], S.bmeta, o);
-    if (L < kTile) {
+    copy_in<T>(&R.pos[0][0][0], S.bpos, p0); copy_in<T>(&R.rot[0][0][0], S.brot, p0);
+    copy_in<T>(&R.u.vel.lin[0][0][0], S.blin, p0); copy_in<T>(&R.u.vel.ang[0][0][0], S.bang, p0);
+    copy_in<T>(&R.meta[0][0], S.bmeta, p0);
+    if (L < T) {
         const int w = S.worldOfSlot[S.wbeg + L];      // which world lives in this slot (k_balance moves them)
         R.wid[L] = w;
         R.numWalls[L] = w >= 0 ? (unsigned char)S.numWalls[w] : 0;
@@ -1537,7 +1562,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         R.seen[L] = 0; R.ndd[L] = 0; R.nsc[L] = 0;
         R.wallSeen[L] = w >= 0 ? (unsigned)S.wallHist[w] : 0u;
     }
-    if (L < 4 * kTile) (&R.plane0[0][0])[L] = S.planes((L >> 3) * kMaxPlanes, S.wbeg + (L & 7));
+    if (L < 4 * T) (&R.plane0[0][0])[L] = S.planes((L / T) * kMaxPlanes, S.wbeg + (L % T));
     wave_sync();
     HS_TICK(9)
     phase_pre(S, R);
@@ -1555,7 +1580,7 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
 #pragma unroll
             for (int c = 0; c < ROUNDS; ++c) {
                 const int t = c * 64 + L;
-                const int ord = t >> 3, g = t & 7;
+                const int ord = t / T, g = t % T;
                 const int slot = ord < S.A ? kAgentSlot0 + ord : ord - S.A;
                 const bool hist = ord < NS && ((R.wallSeen[g] >> slot) & 1u) != 0u;
                 const bool on = ord < NS && R.meta[slot][g] != 0 && hist == (pass == 0);
@@ -1567,12 +1592,12 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
         nbodies = base;
     }
     wave_sync();
-    if (L < kTile) R.wallSeen[L] = 0u;                // from here on: this step's
+    if (L < T) R.wallSeen[L] = 0u;                // from here on: this step's
     wave_sync();
     // A body keeps its (round, lane) for the whole step: which body it is comes from the list, its ground manifold
     // stays in registers.
     BodyReg br[ROUNDS];
-    const float *const aforce = S.aforce.octet(o);
+    const float *const aforce = S.aforce.octet(p0 >> 3) + (p0 & 7);
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         BodyReg &b = br[r];
@@ -1601,16 +1626,16 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
     phase_post(S, R);
     wave_sync();
     // ---- LDS -> the octet's columns
-    copy_out(S.bpos, o, &R.pos[0][0][0]); copy_out(S.brot, o, &R.rot[0][0][0]);
-    copy_out_vel(S.blin, o, &R.u.vel.lin[0][0][0], R); copy_out_vel(S.bang, o, &R.u.vel.ang[0][0][0], R);
-    copy_out(S.bmeta, o, &R.meta[0][0]);
+    copy_out<T>(S.bpos, p0, &R.pos[0][0][0]); copy_out<T>(S.brot, p0, &R.rot[0][0][0]);
+    copy_out_vel(S.blin, p0, &R.u.vel.lin[0][0][0], R); copy_out_vel(S.bang, p0, &R.u.vel.ang[0][0][0], R);
+    copy_out<T>(S.bmeta, p0, &R.meta[0][0]);
     mem_sync();                           // the write-back is complete before a regenerated level overwrites it
     HS_CTICK(8, 9)
     // resetSystem, one lane per world: step counter, or a whole new level on the 240th step / on request
     // (the generator works in the LDS the octet no longer needs: hs_k_reset.h GenScratch)
     {
-        const int myWorld = L < kTile ? R.wid[L] : -1;
-        const int mySeen = L < kTile ? (int)R.wallSeen[L] : 0;
+        const int myWorld = L < T ? R.wid[L] : -1;
+        const int mySeen = L < T ? (int)R.wallSeen[L] : 0;
         wave_sync();                      // every lane has read what it needs from the resident set
         if (myWorld >= 0) {
             S.wallHist[myWorld] = mySeen;
@@ -1631,17 +1656,20 @@ HSD void physics_step(SimState &S, OctRes &R, GenScratch *gen) {
 // -DHS_EXP_REGCAP=W (development aid): the kernel under the register budget of W waves per SIMD — the LDS becomes a dynamic
 // allocation (with the static 20 KiB the compiler knows that W > 2 is unattainable and ignores the request); occupancy on the
 // part stays at two waves per SIMD (LDS), so what the run shows is the cost of the spills alone.
-template <int ROUNDS>
+// -DHS_EXP_REGCAP=W (development aid): the 8-world kernel under the register budget of W waves per SIMD — its LDS becomes a
+// dynamic allocation (with the static 20 KiB the compiler knows that W > 2 is unattainable and ignores the request);
+// occupancy on the part stays at two waves per SIMD (LDS), so what the run shows is the cost of the spills alone.
+template <int ROUNDS, int T>
 #ifdef HS_EXP_REGCAP
 __global__ void __launch_bounds__(kPhysThreads) __attribute__((amdgpu_waves_per_eu(HS_EXP_REGCAP, HS_EXP_REGCAP))) k_physics(SimState S) {
-    union PhysLds { OctRes R; GenScratch gen[kTile]; };
+    union PhysLds { OctResT<T> R; GenScratch gen[T]; };
     extern __shared__ __attribute__((aligned(16))) char dynlds[];
     PhysLds &lds = *reinterpret_cast<PhysLds *>(dynlds);
 #else
-__global__ void __launch_bounds__(kPhysThreads, 2) k_physics(SimState S) {
-    // (the generator's working memory — the reset at the tail of the step — shares the octet's LDS: hs_k_reset.h GenScratch)
-    __shared__ union PhysLds { OctRes R; GenScratch gen[kTile]; } lds;
-    static_assert(sizeof(PhysLds) <= 20 * 1024, "8 octets share the CU's 160 KiB of LDS");
+__global__ void __launch_bounds__(kPhysThreads, T == 8 ? 2 : 4) k_physics(SimState S) {
+    // (the generator's working memory — the reset at the tail of the step — shares the tile's LDS: hs_k_reset.h GenScratch)
+    __shared__ union PhysLds { OctResT<T> R; GenScratch gen[T]; } lds;
+    static_assert(sizeof(PhysLds) <= (T == 8 ? 20 : 10) * 1024, "8 waves of 8 worlds / 16 waves of 4 worlds share the CU's 160 KiB of LDS");
 #endif
     physics_step<ROUNDS>(S, lds.R, lds.gen);
 }

@@ -92,8 +92,12 @@ struct SimState {
     int *spInfo;              // [slots][18] totals (body-body | body-static << 16), per body: first spilled static | count << 16
     int *status;           // [4] sticky counters: body-body / body-static candidate pairs that took the spill path, -, -
                            // (include/hideseek.h hs_device_status); bumped only when something happens
-    long long *phaseTicks; // [octets][10] accumulated per-phase ticks (HS_PHASE_TIMING builds only)
+    long long *phaseTicks; // [physics waves][10] accumulated per-phase ticks, then k_observe's sections and the convex tests'
+                           // counters from phase_ticks_obs_base() on (HS_PHASE_TIMING builds only)
 };
+
+// phaseTicks: the physics waves' part is sized for the finer tile (4 worlds per wave)
+__host__ __device__ inline size_t phase_ticks_obs_base(int N) { return (size_t)10 * ((N + kTile - 1) / kTile * 2); }
 
 HSD int cnt_hiders(int c) { return c & 15; }
 HSD int cnt_seekers(int c) { return (c >> 4) & 15; }

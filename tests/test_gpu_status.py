@@ -90,6 +90,19 @@ def test_pairs_beyond_the_lds_capacities_spill_and_nothing_is_dropped(hiders, se
     assert normal[4] == "0"
 
 
+def test_four_worlds_per_wave_gives_the_same_trajectory():
+    """HS_TILE=4: the physics kernel with a wave per HALF octet (four waves per SIMD, 10 KiB of LDS, 128 registers) instead
+    of a wave per octet — the same templated code with 16 lanes per world.  Oracle parity over 120 steps with joints and
+    locks live, and the digest of the default tiling."""
+    code = PARITY_LOOP % (os.path.join(ROOT, "oracle"), 100, 3, 3, 13, 120)
+    a = [l for l in _child(code, {"HS_TILE": "4"}, timeout=900).splitlines() if l.startswith("PARITY")][0].split()
+    b = [l for l in _child(code, {"HS_TILE": "8"}, timeout=900).splitlines() if l.startswith("PARITY")][0].split()
+    assert a[1] == b[1] and a[4] == "0"
+    code = PARITY_LOOP % (os.path.join(ROOT, "oracle"), 77, 2, 2, 0, 60)          # a world count with partial tiles, 4 agents: one round of bodies
+    a = [l for l in _child(code, {"HS_TILE": "4"}, timeout=900).splitlines() if l.startswith("PARITY")][0].split()
+    assert a[4] == "0"
+
+
 def test_spill_counters_and_graph_flag_are_reported():
     import build as hs_build
     out = _child(STEP_LOOP, {"HS_LIB_PATH": hs_build.build_smallcap()})
