@@ -360,7 +360,10 @@ HSD ItemCounts phase_detect(const SimState &S, OR &R, int NS) {
     }
     // The loops run over the OTHER body / the wall, each read from LDS once and tested against all of the lane's slots.
     // (no branch on the other body's presence: the loads of several trips are in flight together)
-#pragma unroll 4
+    // (one body slot per lane — the 4-world wave — rolled: unrolled, its comparisons are kept as lane masks in scalar
+    // registers, a thousand of which then spill)
+    constexpr int kDetUnroll = JB == 1 ? 1 : 4;
+#pragma unroll kDetUnroll
     for (int j = 1; j < NS; ++j) {
         const int mj = R.meta[j][g];
         const bool dynj = meta_resp(mj) == RESP_DYNAMIC;
