@@ -67,9 +67,9 @@ print("PARITY", h.hexdigest(), st["spilled_dd_pairs"], st["spilled_static_pairs"
 """
 
 
-def _parity(lib, worlds, hiders, seekers, flags, steps):
+def _parity(lib, worlds, hiders, seekers, flags, steps, env=None):
     code = PARITY_LOOP % (os.path.join(ROOT, "oracle"), worlds, hiders, seekers, flags, steps)
-    out = _child(code, {"HS_LIB_PATH": lib} if lib else None, timeout=900)
+    out = _child(code, {**({"HS_LIB_PATH": lib} if lib else {}), **(env or {})}, timeout=900)
     return [l for l in out.splitlines() if l.startswith("PARITY")][0].split()
 
 
@@ -101,6 +101,10 @@ def test_four_worlds_per_wave_gives_the_same_trajectory():
     code = PARITY_LOOP % (os.path.join(ROOT, "oracle"), 77, 2, 2, 0, 60)          # a world count with partial tiles, 4 agents: one round of bodies
     a = [l for l in _child(code, {"HS_TILE": "4"}, timeout=900).splitlines() if l.startswith("PARITY")][0].split()
     assert a[4] == "0"
+    # ... and its spill path: capacities of one pair of each kind
+    import build as hs_build
+    small = _parity(hs_build.build_smallcap(), 64, 3, 3, 13, 90, env={"HS_TILE": "4"})
+    assert int(small[3]) > 0 and small[4] == "0", small
 
 
 def test_spill_counters_and_graph_flag_are_reported():
