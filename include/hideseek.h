@@ -282,6 +282,11 @@ int32_t hs_debug_sat_counters(hs_sim *sim, int64_t out[16]);
 int32_t hs_debug_dump_hull(int32_t obj, float *verts, int32_t *faces, int32_t *counts, float *normals, int32_t *edges,
                            float *local);
 
+/* The DEVICE's object table for one SimObject: out[6] = inverse mass, static / dynamic friction coefficient, inverse inertia x y z
+ * (object frame) as the kernels use them (csrc/hs_dev.h).  tests/test_gpu_hulls.py pins the first three and the zeroed
+ * inertia axes of the agents to tests/golden/object_table.json (src/mgr.cpp:441-588). */
+int32_t hs_debug_object_params(int32_t obj, float *out);
+
 /* Profiling aid: one dword-per-lane coalesced copy of `bytes` bytes (read + write), used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the simulator's access pattern. */
 int32_t hs_debug_calibrate(int64_t bytes);

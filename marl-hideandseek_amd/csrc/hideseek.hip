@@ -781,6 +781,23 @@ int32_t hs_debug_dump_hull(int32_t obj, float *verts, int32_t *faces, int32_t *c
     return HS_OK;
 }
 
+__global__ void k_object_params(int obj, float *out) {
+    using namespace hs;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const V3 i = obj_inv_inertia(obj);
+    out[0] = obj_inv_mass(obj); out[1] = obj_mu_s(obj); out[2] = obj_mu_d(obj); out[3] = i.x; out[4] = i.y; out[5] = i.z;
+}
+int32_t hs_debug_object_params(int32_t obj, float *out) {
+    if (!out || obj < 0 || obj > hs::OBJ_BOX) return fail(HS_ERR_INVALID_ARG, "bad argument");
+    float *d = nullptr;
+    HS_HIP(hipMalloc((void **)&d, 6 * sizeof(float)));
+    hipLaunchKernelGGL(k_object_params, dim3(1), dim3(64), 0, nullptr, (int)obj, d);
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(out, d, 6 * sizeof(float), hipMemcpyDeviceToHost));
+    HS_HIP(hipFree(d));
+    return HS_OK;
+}
+
 // DLPack deleter for the non-owning tensor views handed to Python: the simulator owns the memory, the
 // binding keeps the DLManagedTensor records alive, so there is nothing to free (and nothing here may call
 // back into an interpreter that is shutting down).

@@ -226,7 +226,7 @@ struct RNG {
 };
 
 // ---- object tables: src/mgr.cpp:476-559,577-584 ----
-HSD float obj_inv_mass(int o) { return (o == OBJ_CUBE || o == OBJ_RAMP || o == OBJ_BOX) ? 0.5f : ((o == OBJ_HIDER || o == OBJ_SEEKER) ? 1.f : 0.f); }
+HSD float obj_inv_mass(int o) { return (o == OBJ_CUBE || o == OBJ_RAMP || o == OBJ_BOX) ? 0.5f : ((o == OBJ_HIDER || o == OBJ_SEEKER || o == OBJ_SPHERE) ? 1.f : 0.f); }
 HSD float obj_mu_s(int o) { return o == OBJ_PLANE ? 2.f : 0.5f; }
 HSD float obj_mu_d(int o) {
     return (o == OBJ_PLANE || o == OBJ_CUBE || o == OBJ_WALL) ? 2.f

@@ -69,8 +69,17 @@ def lib():
         L.hsref_collide.restype = C.c_int32
         L.hsref_hull_tables.argtypes = [C.c_int32] + [C.c_void_p] * 6
         L.hsref_hull_tables.restype = None
+        L.hsref_object_params.argtypes = [C.c_int32, C.c_void_p]
+        L.hsref_object_params.restype = None
         _lib = L
     return _lib
+
+
+def object_params(obj):
+    """(inv_mass, mu_s, mu_d, inv_inertia xyz) of SimObject `obj` as the oracle's solver uses them."""
+    out = np.zeros(6, np.float32)
+    lib().hsref_object_params(int(obj), out.ctypes.data)
+    return out
 
 
 def hull_tables(obj):

@@ -150,4 +150,11 @@ void hsref_hull_tables(int32_t obj, float *verts, int32_t *faces, int32_t *count
     aabb[0] = a.lo.x; aabb[1] = a.lo.y; aabb[2] = a.lo.z; aabb[3] = a.hi.x; aabb[4] = a.hi.y; aabb[5] = a.hi.z;
 }
 
+// inverse mass, static / dynamic friction, inverse inertia (object frame) of one SimObject as the solver uses them:
+// tests/test_oracle_hulls.py pins the first three and the zeroed inertia axes to tests/golden/object_table.json (mgr.cpp:441-588)
+void hsref_object_params(int32_t obj, float *out) {
+    V3 i = obj_inv_inertia(obj);
+    out[0] = obj_inv_mass(obj); out[1] = obj_mu_s(obj); out[2] = obj_mu_d(obj); out[3] = i.x; out[4] = i.y; out[5] = i.z;
+}
+
 }  // extern "C"

@@ -33,7 +33,7 @@ constexpr float kMaxDepenVel = 3.f;         // m/s, rate limit for pre-existing 
 static inline float obj_inv_mass(int32_t o) {
     switch (o) {
     case OBJ_CUBE: case OBJ_RAMP: case OBJ_BOX: return 0.5f;
-    case OBJ_HIDER: case OBJ_SEEKER: return 1.f;
+    case OBJ_HIDER: case OBJ_SEEKER: case OBJ_SPHERE: return 1.f;   // (no level ever makes a sphere; the table has it)
     default: return 0.f;
     }
 }

@@ -6,8 +6,26 @@ import os
 
 import numpy as np
 
+import json
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hulls.npz")
-NAMES = {2: "cube", 3: "wall", 4: "agent", 5: "agent", 6: "ramp", 7: "elongated"}      # SimObject -> mesh (src/mgr.cpp:476-559)
+OBJECT_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "object_table.json")
+# SimObject id -> collision mesh, as the reference's loadPhysicsObjects assigns them (tests/golden/object_table.json)
+NAMES = {o["id"]: o["mesh"].replace("_collision.obj", "") for o in json.load(open(OBJECT_TABLE))["objects"].values() if o["mesh"]}
+assert NAMES == {2: "cube", 3: "wall", 4: "agent", 5: "agent", 6: "ramp", 7: "elongated"}
+
+
+def check_object_params(obj, params):
+    """params = (inv_mass, mu_s, mu_d, inv_inertia xyz) of SimObject id `obj` against the reference's table."""
+    tab = {o["id"]: o for o in json.load(open(OBJECT_TABLE))["objects"].values()}[obj]
+    assert float(params[0]) == tab["inv_mass"] and float(params[1]) == tab["mu_s"] and float(params[2]) == tab["mu_d"], (obj, params, tab)
+    for k, ax in enumerate("xyz"):
+        if ax in tab["inv_inertia_zeroed"]:
+            assert float(params[3 + k]) == 0.0, (obj, ax)
+    if tab["inv_inertia_zeroed"] == ["x", "y"]:
+        assert float(params[5]) > 0.0, "a yaw-only body still turns about z"
+    if tab["inv_mass"] > 0 and tab["mesh"] and not tab["inv_inertia_zeroed"]:
+        assert (params[3:6] > 0).all(), "a movable hull has a full inverse inertia"
 
 
 def newell(points):

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from hull_check import check_hull
+from hull_check import check_hull, check_object_params
 
 pytestmark = pytest.mark.gpu
 
@@ -36,3 +36,15 @@ def test_device_hull_tables_match_the_reference_meshes_and_the_oracle(oracle, ob
     assert np.array_equal(t["verts"], o["verts"]) and t["faces"] == o["faces"] and np.array_equal(t["edges"], o["edges"])
     assert np.array_equal(t["normals"].view(np.int32) & 0x7fffffff, o["normals"].view(np.int32) & 0x7fffffff)   # (sign of zero aside)
     assert np.array_equal(np.sign(t["normals"]), np.sign(o["normals"]))
+
+
+@pytest.mark.parametrize("obj", range(8))
+def test_device_object_table_matches_the_reference_and_the_oracle(oracle, obj):
+    import gpu_hideseek
+    L = gpu_hideseek._native.load()
+    L.hs_debug_object_params.argtypes = [C.c_int32, C.c_void_p]
+    L.hs_debug_object_params.restype = C.c_int32
+    out = np.zeros(6, np.float32)
+    assert L.hs_debug_object_params(obj, out.ctypes.data) == 0
+    check_object_params(obj, out)
+    assert np.array_equal(out.view(np.int32), oracle.object_params(obj).view(np.int32))

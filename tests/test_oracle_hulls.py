@@ -6,7 +6,7 @@ exactly those meshes."""
 import numpy as np
 import pytest
 
-from hull_check import check_hull, GOLDEN
+from hull_check import check_hull, check_object_params, GOLDEN
 
 
 @pytest.mark.parametrize("obj", [2, 3, 4, 5, 6, 7])
@@ -26,3 +26,10 @@ def test_fixture_is_what_the_reference_ships():
     assert g["ramp_v"].shape == (6, 3) and sorted((row >= 0).sum() for row in g["ramp_f"]) == [3, 3, 4, 4, 4]
     assert g["wall_lo"].tolist() == [-1, -1, 0] and g["wall_hi"].tolist() == [1, 1, 2.5]
     assert g["ramp_lo"].tolist() == [-1, -2, -1] and g["elongated_hi"].tolist() == [4, 0.75, 1]
+
+
+@pytest.mark.parametrize("obj", range(8))
+def test_oracle_object_table_matches_the_reference(oracle, obj):
+    """Inverse masses, friction coefficients and the yaw-only "HACK" of loadPhysicsObjects (src/mgr.cpp:476-584), read out of
+    the reference's source into tests/golden/object_table.json by tests/golden/gen_object_table_fixture.py."""
+    check_object_params(obj, oracle.object_params(obj))
