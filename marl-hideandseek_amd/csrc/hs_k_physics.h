@@ -1,9 +1,12 @@
 // Physics step: movement / actions, PhysicsSystem::setupPhysicsStepTasks (src/sim.cpp:1162-1163; engine
 // source absent — DESIGN.md "Engine decisions") and the reward systems as ONE kernel, ONE WAVE PER OCTET.
+// (Everything below is templated on the tile T = worlds per wave: T = 8, the octet, is the default and what the text
+// describes; T = 4 — HS_TILE=4, a wave per half octet, 16 lanes per world, four waves per SIMD — is the same code, bit-exact,
+// and measured 8 - 10 % slower: DESIGN.md §5.)
 //
 // A workgroup is a single 64-lane wave that owns 8 consecutive worlds (an octet, hs_state.h) for the whole step.
 // The octet's working set — pose, previous pose, velocities and meta word of every body — is copied from its
-// contiguous blocks of the tiled columns into LDS once (struct OctRes, 20 KiB: 8 such waves share a CU's 160 KiB),
+// contiguous blocks of the tiled columns into LDS once (struct OctResT<8>, 20 KiB: 8 such waves share a CU's 160 KiB),
 // stays there through movement, the four XPBD substeps and the rewards, and is copied back once.  Nothing in the
 // step is shared between waves, so there is NO barrier between waves anywhere: a wave walks its own worlds
 // through the phases at its own pace while the other wave of its SIMD fills its stalls.  (The round-1 kernel ran
