@@ -398,7 +398,7 @@ HSD ItemCounts phase_detect(const SimState &S, OR &R, int NS) {
         wall_test(k, S.walls(0 * kMaxWalls + k, w), S.walls(1 * kMaxWalls + k, w), S.walls(2 * kMaxWalls + k, w), S.walls(3 * kMaxWalls + k, w));
     }
     // candidate slots in the world's lists: prefix sums in body-slot order (slots l of all lanes, then l + 8, ...),
-    // i.e. the oracle's candidate order — so even the pairs dropped beyond the capacity are the oracle's
+    // i.e. the oracle's candidate order — a pair's place in it is where its record lives in the workspace
     int tot_dd = 0, tot_sc = 0;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {

@@ -305,7 +305,7 @@ class HideAndSeekSimulator:
                 "graphs_in_use": bool(st.graphs_in_use)}
 
     def warning(self):
-        """The library's last message for this thread (a warning after a successful call, e.g. dropped pairs)."""
+        """The library's last message for this thread."""
         return self._L.hs_last_error().decode()
 
     # ---- parity-test hooks (include/hideseek.h hs_debug_dump_*) ----
