@@ -53,7 +53,9 @@ struct hs_sim {
     bool balance = true;
     int balance_period = 32, steps_since_balance = 0;
     int *bal_hist = nullptr, *bal_cursor = nullptr, *bal_new_slot = nullptr;
-    void *bal_tmp = nullptr; size_t bal_tmp_bytes = 0;
+    void *bal_tmp = nullptr;               // a second arena: the deal copies the columns there and moves them back to their new slots
+    void *col_arena = nullptr; size_t col_arena_bytes = 0, col_slots = 0;      // the tiled columns, one after the other
+    hs::BalanceCols bal_cols;              // first arena row of each column (+ the total)
     hipStream_t stream = nullptr;          // this handle's own stream: hs_init / hs_step / checkpoints run here
     hipEvent_t evIn = nullptr;             // orders `stream` after the device's legacy default stream (torch's writes to `action`)
     bool step_open = false;                // hs_step_begin without its hs_step_end
@@ -149,16 +151,8 @@ int launch_step_eager(hs_sim *s, hipStream_t strm, bool first, bool prof, int st
     return HS_OK;
 }
 
-// Deal the worlds to the octets by contact load (hs_k_balance.h): a handful of small launches every balance_period steps.
-template <typename T, int ROWS>
-int balance_move(hs_sim *s, hipStream_t strm, const hs::Col<T, ROWS> &col, int nfull) {
-    const size_t bytes = (size_t)ROWS * ((s->S.N + hs::kTile - 1) / hs::kTile * hs::kTile) * sizeof(T);
-    HS_HIP(hipMemcpyAsync(s->bal_tmp, col.p, bytes, hipMemcpyDeviceToDevice, strm));
-    const int n = nfull * ROWS;
-    hipLaunchKernelGGL(hs::k_balance_move<T>, dim3((n + 255) / 256), dim3(256), 0, strm, col.p, (const T *)s->bal_tmp, ROWS,
-                       (const int *)s->S.slotOfWorld, (const int *)s->bal_new_slot, nfull);
-    return HS_OK;
-}
+// Deal the worlds to the octets by contact load (hs_k_balance.h), every balance_period steps: histogram, scan, deal, one copy
+// of the column arena, one move kernel over all columns, commit (six launches and a copy; it was 26 launches and 11 copies).
 int balance_worlds(hs_sim *s, hipStream_t strm) {
     const hs::SimState &S = s->S;
     const int nfull = S.N / hs::kTile * hs::kTile;
@@ -167,13 +161,10 @@ int balance_worlds(hs_sim *s, hipStream_t strm) {
     hipLaunchKernelGGL(hs::k_balance_hist, grid, blk, 0, strm, S, nfull, s->bal_hist);
     hipLaunchKernelGGL(hs::k_balance_scan, dim3(1), dim3(hs::kBalanceBins), 0, strm, s->bal_hist, s->bal_cursor);
     hipLaunchKernelGGL(hs::k_balance_deal, grid, blk, 0, strm, S, nfull, s->bal_cursor, s->bal_new_slot, s->tile);
-    int rc;
-    if ((rc = balance_move(s, strm, S.bpos, nfull)) != HS_OK || (rc = balance_move(s, strm, S.brot, nfull)) != HS_OK ||
-        (rc = balance_move(s, strm, S.blin, nfull)) != HS_OK || (rc = balance_move(s, strm, S.bang, nfull)) != HS_OK ||
-        (rc = balance_move(s, strm, S.bmeta, nfull)) != HS_OK || (rc = balance_move(s, strm, S.aforce, nfull)) != HS_OK ||
-        (rc = balance_move(s, strm, S.walls, nfull)) != HS_OK || (rc = balance_move(s, strm, S.planes, nfull)) != HS_OK ||
-        (rc = balance_move(s, strm, S.runningScores, nfull)) != HS_OK || (rc = balance_move(s, strm, S.grabOther, nfull)) != HS_OK ||
-        (rc = balance_move(s, strm, S.grabData, nfull)) != HS_OK) return rc;
+    HS_HIP(hipMemcpyAsync(s->bal_tmp, s->col_arena, s->col_arena_bytes, hipMemcpyDeviceToDevice, strm));
+    const size_t n = (size_t)nfull * s->bal_cols.base[hs::kBalanceCols];
+    hipLaunchKernelGGL(hs::k_balance_move_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, strm, (int *)s->col_arena, (const int *)s->bal_tmp,
+                       s->bal_cols, s->col_slots, (const int *)s->S.slotOfWorld, (const int *)s->bal_new_slot, nfull);
     hipLaunchKernelGGL(hs::k_balance_commit, grid, blk, 0, strm, S, nfull, (const int *)s->bal_new_slot);
     HS_HIP(hipGetLastError());
     return HS_OK;
@@ -289,11 +280,24 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
 #define HS_ALLOC(ptr, n) if ((rc = s->dalloc(&(ptr), (n))) != HS_OK) { hs_destroy(s); return rc; }
     // tiled columns (hs_state.h Col): whole octets, the padding worlds stay zero = empty slots
     const size_t NP = (N + hs::kTile - 1) / hs::kTile * hs::kTile;
-#define HS_ALLOC_COL(col) HS_ALLOC((col).p, (size_t)(col).kRows * NP)
-    HS_ALLOC_COL(S.bpos); HS_ALLOC_COL(S.brot); HS_ALLOC_COL(S.blin); HS_ALLOC_COL(S.bang); HS_ALLOC_COL(S.bmeta);
-    HS_ALLOC_COL(S.aforce); HS_ALLOC_COL(S.walls); HS_ALLOC_COL(S.planes);
-    HS_ALLOC_COL(S.runningScores); HS_ALLOC_COL(S.grabOther); HS_ALLOC_COL(S.grabData);
-#undef HS_ALLOC_COL
+    // the tiled columns are consecutive pieces of ONE arena (so that the periodic deal moves them in one launch): all have
+    // 4-byte elements; a column of ROWS rows takes ROWS * NP of them
+    {
+        const int rows[hs::kBalanceCols] = {S.bpos.kRows, S.brot.kRows, S.blin.kRows, S.bang.kRows, S.bmeta.kRows, S.aforce.kRows, S.walls.kRows,
+                                            S.planes.kRows, S.runningScores.kRows, S.grabOther.kRows, S.grabData.kRows};
+        s->bal_cols.base[0] = 0;
+        for (int k = 0; k < hs::kBalanceCols; ++k) s->bal_cols.base[k + 1] = s->bal_cols.base[k] + rows[k];
+        s->col_slots = NP;
+        s->col_arena_bytes = (size_t)s->bal_cols.base[hs::kBalanceCols] * NP * 4;
+        char *arena, *tmp;
+        HS_ALLOC(arena, s->col_arena_bytes); HS_ALLOC(tmp, s->col_arena_bytes);
+        s->col_arena = arena; s->bal_tmp = tmp;
+        int k = 0;
+#define HS_ARENA_COL(col) (col).p = (decltype((col).p))(arena + (size_t)s->bal_cols.base[k++] * NP * 4);
+        HS_ARENA_COL(S.bpos) HS_ARENA_COL(S.brot) HS_ARENA_COL(S.blin) HS_ARENA_COL(S.bang) HS_ARENA_COL(S.bmeta) HS_ARENA_COL(S.aforce)
+        HS_ARENA_COL(S.walls) HS_ARENA_COL(S.planes) HS_ARENA_COL(S.runningScores) HS_ARENA_COL(S.grabOther) HS_ARENA_COL(S.grabData)
+#undef HS_ARENA_COL
+    }
     HS_ALLOC(S.numWalls, N); HS_ALLOC(S.numPlanes, N);
     HS_ALLOC(S.curWorldEpisode, N); HS_ALLOC(S.rngKeyA, N); HS_ALLOC(S.rngKeyB, N); HS_ALLOC(S.rngCount, N);
     HS_ALLOC(S.curEpisodeStep, N); HS_ALLOC(S.hiderTeamReward, N); HS_ALLOC(S.counts, N); HS_ALLOC(S.teams, N);
@@ -313,7 +317,6 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     HS_ALLOC(S.lidarSinCos, 60);
     HS_ALLOC(S.octTicks, NP / 4); HS_ALLOC(S.tickSum, 3);
     HS_ALLOC(s->bal_hist, hs::kBalanceBins); HS_ALLOC(s->bal_cursor, hs::kBalanceBins); HS_ALLOC(s->bal_new_slot, N);
-    { char *tmp; s->bal_tmp_bytes = (size_t)S.walls.kRows * NP * sizeof(float); HS_ALLOC(tmp, s->bal_tmp_bytes); s->bal_tmp = tmp; }
     HS_ALLOC(S.status, 4);
 #undef HS_ALLOC
     // Sim::Sim (sim.cpp:1346-1408): resetLevel = 1 for every world, no grab joints

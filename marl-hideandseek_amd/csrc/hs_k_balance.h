@@ -48,14 +48,22 @@ __global__ void __launch_bounds__(256) k_balance_deal(SimState S, int nfull, int
     newSlot[w] = ((row & 1) ? noct - 1 - col : col) * tile + row;
     S.loadAcc[w] = 0;
 }
-// 4. the rows of one column move from the old slot to the new one (out of place: src is a copy of the column)
-template <typename T>
-__global__ void __launch_bounds__(256) k_balance_move(T *dst, const T *src, int rows, const int *oldSlot, const int *newSlot, int nfull) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (world, row) with the world fastest
-    if (i >= nfull * rows) return;
-    const int row = i / nfull, w = i - row * nfull;
+// 4. every row of every tiled column moves from the old slot to the new one, in ONE launch: the columns are consecutive
+// pieces of one arena (hideseek.hip), `src` is a copy of the arena, `base` the first arena row of each column (+ the total).
+constexpr int kBalanceCols = 11;
+struct BalanceCols { int base[kBalanceCols + 1]; };
+__global__ void __launch_bounds__(256) k_balance_move_all(int *dst, const int *src, BalanceCols cols, size_t slots, const int *oldSlot,
+                                                          const int *newSlot, int nfull) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // (arena row, world) with the world fastest
+    if (i >= (size_t)nfull * cols.base[kBalanceCols]) return;
+    const int grow = (int)(i / nfull), w = (int)(i - (size_t)grow * nfull);
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < kBalanceCols; ++k) c += grow >= cols.base[k] ? 1 : 0;
+    const int row = grow - cols.base[c], rows = cols.base[c + 1] - cols.base[c];
+    const size_t off = (size_t)cols.base[c] * slots;                           // the column's first element in the arena
     const int a = oldSlot[w], b = newSlot[w];
-    dst[((size_t)(b >> 3) * rows + row) * kTile + (b & 7)] = src[((size_t)(a >> 3) * rows + row) * kTile + (a & 7)];
+    dst[off + ((size_t)(b >> 3) * rows + row) * kTile + (b & 7)] = src[off + ((size_t)(a >> 3) * rows + row) * kTile + (a & 7)];
 }
 // 5. the maps
 __global__ void __launch_bounds__(256) k_balance_commit(SimState S, int nfull, const int *newSlot) {
