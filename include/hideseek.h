@@ -267,6 +267,11 @@ int32_t hs_last_step_kernel_ms(hs_sim *sim, float out_ms[3]);
  * [groups][10] = pre, integrate, detect, sat, dd_pos, body_pos, dd_vel, body_vel, post, -; all zero unless the
  * library was built with -DHS_PHASE_TIMING.  Returns the number of groups written (<= max_groups). */
 int32_t hs_debug_phase_ticks(hs_sim *sim, int64_t *out, int32_t max_groups);
+/* Development aid: work counters per WORLD, accumulated since init, [worlds][8] = body-body candidates, body-static
+ * candidates, accepted body-body manifolds, body-body solver rounds the world was pending in, the physics wave the world
+ * lives in, the solver rounds that wave ran (first world of a wave only), -, -; all zero unless the library was built with
+ * -DHS_LOAD_STUDY (tools/load_study.py).  Returns the number of worlds written (<= max_worlds). */
+int32_t hs_debug_load_study(hs_sim *sim, int64_t *out, int32_t max_worlds);
 /* The same for k_observe: ticks per section, summed over all waves: stage (incl. the schedule's wait), per-agent table,
  * ray setup, walls, planes, hull cull, exact hull tests, ray results, observation rows. */
 int32_t hs_debug_observe_ticks(hs_sim *sim, int64_t out[16]);

@@ -311,7 +311,7 @@ int32_t hs_create(const hs_config *cfg, hs_sim **out) {
     // (every possible pair of every world: 92 KB per world, 1.5 GB at 16 000 worlds, of which a step touches a few MB)
     { char *p; HS_ALLOC(p, NP * hs::kAllDD * sizeof(hs::ManDD)); S.wsDD = p; HS_ALLOC(p, NP * hs::kAllSC * sizeof(hs::ManS)); S.wsSC = p; }
     HS_ALLOC(S.spPair, NP * (hs::kAllDD + hs::kAllSC)); HS_ALLOC(S.spInfo, NP * hs::kSpInfoWords);
-    HS_ALLOC(S.phaseTicks, hs::phase_ticks_obs_base((int)N) + 16 * 1024 + 16);     // + 1024 x 16 section counters of k_observe
+    HS_ALLOC(S.phaseTicks, hs::phase_ticks_study_base((int)N) + N * hs::kStudyWords);   // + k_observe's section counters + the per-world work counters
     HS_ALLOC(S.slotOfWorld, N); HS_ALLOC(S.worldOfSlot, NP); HS_ALLOC(S.loadAcc, N); HS_ALLOC(S.wallHist, N);
     if ((rc = s->dalloc(&S.slotHdr, NP, 0xFF)) != HS_OK) { hs_destroy(s); return rc; }      // world id -1: empty slot
     HS_ALLOC(S.lidarSinCos, 60);
@@ -657,6 +657,15 @@ int32_t hs_debug_phase_ticks(hs_sim *s, int64_t *out, int32_t max_groups) {
     if (nb > max_groups) nb = max_groups;
     HS_HIP(hipMemcpy(out, s->S.phaseTicks, (size_t)nb * 10 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return nb;
+}
+
+// Per-world work counters (HS_LOAD_STUDY builds): [worlds][8], see hs_state.h phase_ticks_study_base.
+int32_t hs_debug_load_study(hs_sim *s, int64_t *out, int32_t max_worlds) {
+    if (!s || !out) return fail(HS_ERR_INVALID_ARG, "null argument");
+    HS_HIP(hipSetDevice(s->cfg.gpu_id));
+    const int n = s->S.N < max_worlds ? s->S.N : max_worlds;
+    HS_HIP(hipMemcpy(out, s->S.phaseTicks + hs::phase_ticks_study_base(s->S.N), (size_t)n * hs::kStudyWords * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return n;
 }
 
 // The same for k_observe: ticks per section summed over all waves (HS_PHASE_TIMING builds).

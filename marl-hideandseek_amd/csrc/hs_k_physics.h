@@ -478,6 +478,12 @@ HSD ItemCounts phase_detect(const SimState &S, OR &R, int NS) {
         R.ndd[g] = (unsigned char)min(tot_dd, kMaxDDCand); R.nsc[g] = (unsigned char)min(tot_sc, kMaxSCand);
         // what k_balance sorts the worlds by: candidate pairs are where an octet's time differs from another's
         if (R.wid[g] >= 0 && tot_dd + tot_sc > 0) S.loadAcc[R.wid[g]] += HS_LOAD_DD_WEIGHT * tot_dd + tot_sc;
+#ifdef HS_LOAD_STUDY
+        if (R.wid[g] >= 0) {
+            long long *const st = S.phaseTicks + phase_ticks_study_base(S.N) + (size_t)R.wid[g] * kStudyWords;
+            st[0] += tot_dd; st[1] += tot_sc; st[4] = blockIdx.x;
+        }
+#endif
     }
     wave_sync();
     return ic;
@@ -1013,6 +1019,9 @@ HSD void phase_dd(const SimState &S, OR &R, bool anySpill) {
     ManDD *const wsDD = (ManDD *)S.wsDD + (size_t)w * kAllDD;
     const unsigned acc = R.ddAcc[g];
     const int nacc = __popc(acc);
+#ifdef HS_LOAD_STUDY
+    if (POS && q == 0 && R.wid[g] >= 0) S.phaseTicks[phase_ticks_study_base(S.N) + (size_t)R.wid[g] * kStudyWords + 2] += nacc;
+#endif
     if (POS) {
         // The solve order, once per substep (the velocity pass reuses it): kMaxDDCand = 16 candidates, lane q ranks the
         // keys of the accepted ones among q and q+8 (keys are unique: distinct pairs) and enters them at their rank.
@@ -1057,6 +1066,13 @@ HSD void phase_dd(const SimState &S, OR &R, bool anySpill) {
         while (true) {
             const unsigned long long pend_mask = __ballot(pending && isA);
             if (pend_mask == 0ull) break;
+#ifdef HS_LOAD_STUDY
+            if (POS) {
+                long long *const st = S.phaseTicks + phase_ticks_study_base(S.N);
+                if (q == 0 && R.wid[g] >= 0 && ((pend_mask >> gbit0) & ((1ull << GL) - 1ull)) != 0ull) st[(size_t)R.wid[g] * kStudyWords + 3] += 1;
+                if (L == 0 && R.wid[0] >= 0) st[(size_t)R.wid[0] * kStudyWords + 5] += 1;
+            }
+#endif
             // (bit 2p of the world's 8 bits: pair p is pending)
             const unsigned wp = (unsigned)(pend_mask >> gbit0);
             unsigned pendPairs = 0u;
@@ -1526,6 +1542,9 @@ HSD void substep_rest(const SimState &S, OR &R, BodyReg (&br)[ROUNDS], int nbodi
 
 // ROUNDS = rounds of 64 lanes that cover the octet's bodies: 2 up to 16 body slots per world (<= 5 agents), 3 with
 // 6 agents (17 slots x 8 worlds = 136 bodies at most).
+#ifndef HS_EXP_PRIO
+#define HS_EXP_PRIO 1
+#endif
 template <int ROUNDS, class OR>
 HSD void physics_step(SimState &S, OR &R, GenScratch *gen) {
     constexpr int T = OR::kT;
@@ -1540,7 +1559,7 @@ HSD void physics_step(SimState &S, OR &R, GenScratch *gen) {
     // of convex tests instead gave 0.382.
     const long long tStart = wall_clock64();
     // (S.stepIdx < 0: a launch replayed from a HIP graph, whose arguments are frozen at capture — no rotating sums, no hint)
-    if (S.stepIdx < 0) __builtin_amdgcn_s_setprio(2);
+    if (S.stepIdx < 0 || HS_EXP_PRIO == 0) __builtin_amdgcn_s_setprio(2);
     else {
         const int sidx = S.stepIdx, prevIdx = sidx == 0 ? 2 : sidx - 1, nextIdx = sidx == 2 ? 0 : sidx + 1;
         if (o == 0 && L == 0) S.tickSum[nextIdx] = 0ull;
@@ -1649,7 +1668,8 @@ HSD void physics_step(SimState &S, OR &R, GenScratch *gen) {
         }
     }
     if (L == 0 && S.stepIdx >= 0) {
-        const int dt = (int)(wall_clock64() - tStart);
+        const int now = (int)(wall_clock64() - tStart);
+        const int dt = HS_EXP_PRIO == 2 ? (S.octTicks[o] + now) >> 1 : HS_EXP_PRIO == 3 ? (3 * S.octTicks[o] + now) >> 2 : now;
         S.octTicks[o] = dt;
         atomicAdd(&S.tickSum[S.stepIdx], (unsigned long long)dt);
     }

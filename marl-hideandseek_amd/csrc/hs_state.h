@@ -98,6 +98,11 @@ struct SimState {
 
 // phaseTicks: the physics waves' part is sized for the finer tile (4 worlds per wave)
 __host__ __device__ inline size_t phase_ticks_obs_base(int N) { return (size_t)10 * ((N + kTile - 1) / kTile * 2); }
+// ... and after k_observe's part: [N][8] work counters per WORLD (HS_LOAD_STUDY builds, tools/load_study.py): body-body /
+// body-static candidates, accepted body-body manifolds, rounds of the body-body solver the world was pending in,
+// the physics wave it lives in, and — for the first world of a wave — the solver rounds the wave ran
+constexpr int kStudyWords = 8;
+__host__ __device__ inline size_t phase_ticks_study_base(int N) { return phase_ticks_obs_base(N) + 16 * 1024 + 16; }
 
 HSD int cnt_hiders(int c) { return c & 15; }
 HSD int cnt_seekers(int c) { return (c >> 4) & 15; }
