@@ -482,6 +482,8 @@ HSD ItemCounts phase_detect(const SimState &S, OR &R, int NS) {
         if (R.wid[g] >= 0) {
             long long *const st = S.phaseTicks + phase_ticks_study_base(S.N) + (size_t)R.wid[g] * kStudyWords;
             st[0] += tot_dd; st[1] += tot_sc; st[4] = blockIdx.x;
+            // (where the wave runs: HW_ID = wave | simd << 4 | pipe << 6 | cu << 8 | sh << 12 | se << 13 ..., and the XCC)
+            if (g == 0) { st[6] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); st[7] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); }
         }
 #endif
     }
