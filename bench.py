@@ -350,6 +350,27 @@ def main():
             traffic_source = f"unreadable profiles/{tfiles[-1]}: {e}"
     elif tfiles:
         traffic_source = "none: the committed PMC run is for 16000 worlds, sim_flags 0"
+    # What actually bounds the kernels is VALU issue, not HBM: the instruction counts of the committed SQ-counter run of THIS
+    # build (tools/sqpmc.sh -> profiles/*_sq_counters.txt, same fingerprint rule as the traffic) against the rate at which a
+    # SIMD issues f32 VALU instructions with all its wave slots busy (tools/ubench/pk_rate.hip, measured on the part).
+    valu_issue = None
+    sfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_sq_counters.txt"))
+    if sfiles and N == WORLDS_PER_GPU and args.flags == 0:
+        try:
+            txt = open(os.path.join(ROOT, "profiles", sfiles[-1])).read()
+            if f"csrc_sha {csrc_fingerprint()}" in txt:
+                valu_issue = {"source": f"profiles/{sfiles[-1]} (rocprofv3 SQ counters of a 24-step run of this build, window placed like a short bench run; not this run)",
+                              "simd_count": 1024, "issue_ns_per_instruction_and_simd": 1.2,
+                              "peak_source": "tools/ubench/pk_rate.hip: a SIMD with all wave slots busy issues one f32 VALU instruction per 1.2 ns"}
+                for n in kms:
+                    for line in txt.splitlines():
+                        if line.startswith("sq1") and names[n] in line and "SQ_INSTS_VALU=" in line:
+                            insts = float(line.split("SQ_INSTS_VALU=")[1].split()[0])
+                            floor_ms = insts * 1.2e-9 / 1024 * 1e3
+                            valu_issue[n] = {"valu_wave_instructions_per_launch": insts, "issue_bound_ms": floor_ms,
+                                             "frac": floor_ms / (kms[n] / max(nsamp, 1))}
+        except Exception as e:
+            valu_issue = {"source": f"unreadable profiles/{sfiles[-1]}: {e}"}
     step_bytes, step_per_world = algorithmic_bytes(sim, A, "physics_only_step" if skip_obs else "step")
     step_ms = dt / args.steps * 1e3
     roofline = {"bound": "hbm", "kernel": per_stage[dom]["kernel"], "achieved": per_stage[dom]["achieved_GBps"],
@@ -365,6 +386,7 @@ def main():
                 "kernel_ms_per_step": {n: kms[n] / max(nsamp, 1) for n in kms},
                 "kernel_time_samples": {"every": P, "count": nsamp, "how": "HIP events on the launch stream around the kernels of "
                                         "every P-th step of the timed region"},
+                "valu_issue": valu_issue,
                 "schedule": "k_physics then k_observe on one stream"}
 
     if rank == 0:

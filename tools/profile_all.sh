@@ -9,12 +9,13 @@ O=gpurun_out/prof_$tag
 bash tools/pmc.sh > $O/pmc.log 2>&1 || exit 1
 python3 tools/pmc_summary.py gpurun_out $O/traffic.json 16000 > $O/traffic_summary.txt || exit 1
 cp $O/traffic.json profiles/${tag}_traffic.json
+{ python3 -c "import bench; print('csrc_sha', bench.csrc_fingerprint())"; bash tools/sqpmc.sh; } > $O/sq_counters.txt 2>&1 || exit 1
+cp $O/sq_counters.txt profiles/${tag}_sq_counters.txt
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --worlds-per-gpu 65536 --flags 65536 --steps 480 > $O/bench_physics_only_65536.json 2>> $O/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --worlds-per-gpu 16384 --steps 960 > $O/bench_shard_16384.json 2>> $O/bench.err || exit 1
 bash tools/kstats.sh > $O/kstats.txt 2>&1 || exit 1
 cp gpurun_out/kernel_stats.csv $O/kernel_stats.csv; cp gpurun_out/kstats_bench.json $O/kstats_bench.json
-bash tools/sqpmc.sh > $O/sq_counters.txt 2>&1 || exit 1
 HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so timeout -k 10 120 python3 tools/phase_timing.py 16000 2>&1 | grep -v amdgpu.ids > $O/phase_times.txt
 timeout -k 10 200 python3 tools/step_hist.py 2>&1 | grep -v amdgpu.ids > $O/step_hist.txt
 HS_LIB_PATH=$PWD/marl-hideandseek_amd/lib/libhideseek_timing.so timeout -k 10 200 python3 tools/phase_tail.py 16000 240 2>&1 | grep -v amdgpu.ids > $O/phase_tail.txt
