@@ -78,22 +78,24 @@ HSD V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 HSD V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
 HSD V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 HSD V3 mulc(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-HSD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-HSD V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// (fused multiply-adds, written out one by one: the CPU restatement the tests compare with has the same ones in the same places)
+HSD float hs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+HSD float dot(V3 a, V3 b) { return hs_fma(a.z, b.z, hs_fma(a.y, b.y, a.x * b.x)); }
+HSD V3 cross(V3 a, V3 b) { return {hs_fma(a.y, b.z, -(a.z * b.y)), hs_fma(a.z, b.x, -(a.x * b.z)), hs_fma(a.x, b.y, -(a.y * b.x))}; }
 HSD float len2(V3 a) { return dot(a, a); }
 HSD float len(V3 a) { return sqrtf(dot(a, a)); }
 HSD V3 normalize(V3 a) { float inv = 1.f / len(a); return a * inv; }
 HSD V3 vsel(bool c, V3 a, V3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 HSD Q qmul(Q a, Q b) {
-    return {(a.w * b.w - a.x * b.x) - (a.y * b.y + a.z * b.z),
-            (a.w * b.x + a.x * b.w) + (a.y * b.z - a.z * b.y),
-            (a.w * b.y - a.x * b.z) + (a.y * b.w + a.z * b.x),
-            (a.w * b.z + a.x * b.y) - (a.y * b.x - a.z * b.w)};
+    return {hs_fma(-a.z, b.z, hs_fma(-a.y, b.y, hs_fma(-a.x, b.x, a.w * b.w))),
+            hs_fma(-a.z, b.y, hs_fma(a.y, b.z, hs_fma(a.x, b.w, a.w * b.x))),
+            hs_fma(a.z, b.x, hs_fma(a.y, b.w, hs_fma(-a.x, b.z, a.w * b.y))),
+            hs_fma(a.z, b.w, hs_fma(-a.y, b.x, hs_fma(a.x, b.y, a.w * b.z)))};
 }
 HSD Q qinv(Q q) { return {q.w, -q.x, -q.y, -q.z}; }
 HSD Q qnormalize(Q q) {
-    float n2 = (q.w * q.w + q.x * q.x) + (q.y * q.y + q.z * q.z);
+    float n2 = hs_fma(q.z, q.z, hs_fma(q.y, q.y, hs_fma(q.x, q.x, q.w * q.w)));
     float inv = 1.f / sqrtf(n2);
     return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
@@ -101,10 +103,10 @@ HSD V3 qrot(Q q, V3 v) {
     V3 p = {q.x, q.y, q.z};
     float s = q.w;
     float d2 = 2.f * dot(p, v);
-    float k = 2.f * s * s - 1.f;
-    V3 c = cross(p, v);
     float s2 = 2.f * s;
-    return {(d2 * p.x + k * v.x) + s2 * c.x, (d2 * p.y + k * v.y) + s2 * c.y, (d2 * p.z + k * v.z) + s2 * c.z};
+    float k = hs_fma(s2, s, -1.f);
+    V3 c = cross(p, v);
+    return {hs_fma(s2, c.x, hs_fma(d2, p.x, k * v.x)), hs_fma(s2, c.y, hs_fma(d2, p.y, k * v.y)), hs_fma(s2, c.z, hs_fma(d2, p.z, k * v.z))};
 }
 
 // sin/cos by Cody-Waite pi/2 reduction + minimax polynomials; atan2/asin likewise.  These replace

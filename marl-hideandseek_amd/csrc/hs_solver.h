@@ -26,17 +26,17 @@ HSD Sym3 world_inv_inertia(Q q, V3 invI) {
     M3 m = m3_from_quat(q);
     V3 r0 = m.c0 * invI.x, r1 = m.c1 * invI.y, r2 = m.c2 * invI.z;
     Sym3 s;
-    s.xx = (r0.x * m.c0.x + r1.x * m.c1.x) + r2.x * m.c2.x;
-    s.xy = (r0.x * m.c0.y + r1.x * m.c1.y) + r2.x * m.c2.y;
-    s.xz = (r0.x * m.c0.z + r1.x * m.c1.z) + r2.x * m.c2.z;
-    s.yy = (r0.y * m.c0.y + r1.y * m.c1.y) + r2.y * m.c2.y;
-    s.yz = (r0.y * m.c0.z + r1.y * m.c1.z) + r2.y * m.c2.z;
-    s.zz = (r0.z * m.c0.z + r1.z * m.c1.z) + r2.z * m.c2.z;
+    s.xx = hs_fma(r2.x, m.c2.x, hs_fma(r1.x, m.c1.x, r0.x * m.c0.x));
+    s.xy = hs_fma(r2.x, m.c2.y, hs_fma(r1.x, m.c1.y, r0.x * m.c0.y));
+    s.xz = hs_fma(r2.x, m.c2.z, hs_fma(r1.x, m.c1.z, r0.x * m.c0.z));
+    s.yy = hs_fma(r2.y, m.c2.y, hs_fma(r1.y, m.c1.y, r0.y * m.c0.y));
+    s.yz = hs_fma(r2.y, m.c2.z, hs_fma(r1.y, m.c1.z, r0.y * m.c0.z));
+    s.zz = hs_fma(r2.z, m.c2.z, hs_fma(r1.z, m.c1.z, r0.z * m.c0.z));
     return s;
 }
 HSD V3 sym_mul(const Sym3 &s, V3 v) {
-    return {(s.xx * v.x + s.xy * v.y) + s.xz * v.z, (s.xy * v.x + s.yy * v.y) + s.yz * v.z,
-            (s.xz * v.x + s.yz * v.y) + s.zz * v.z};
+    return {hs_fma(s.xz, v.z, hs_fma(s.xy, v.y, s.xx * v.x)), hs_fma(s.yz, v.z, hs_fma(s.yy, v.y, s.xy * v.x)),
+            hs_fma(s.zz, v.z, hs_fma(s.yz, v.y, s.xz * v.x))};
 }
 // call at the start of every manifold / joint (the oracle re-evaluates body_mass there)
 HSD void body_refresh_inertia(BodyS &b) {
@@ -62,8 +62,8 @@ HSD float gen_inv_mass(const BodyS &b, V3 r, V3 n) {
 // q += 0.5 * (0,dth) * q, then one Newton step of 1/sqrt(|q|^2) from 1 (DESIGN.md "Engine decisions")
 HSD Q quat_add_rotation(Q q, V3 dth) {
     Q dq = qmul(Q{0.f, dth.x, dth.y, dth.z}, q);
-    Q r = {q.w + 0.5f * dq.w, q.x + 0.5f * dq.x, q.y + 0.5f * dq.y, q.z + 0.5f * dq.z};
-    const float n2 = ((r.w * r.w + r.x * r.x) + r.y * r.y) + r.z * r.z;
+    Q r = {hs_fma(0.5f, dq.w, q.w), hs_fma(0.5f, dq.x, q.x), hs_fma(0.5f, dq.y, q.y), hs_fma(0.5f, dq.z, q.z)};
+    const float n2 = hs_fma(r.z, r.z, hs_fma(r.y, r.y, hs_fma(r.x, r.x, r.w * r.w)));
     // small updates (|dth| < 0.2 rad: every contact correction, ordinary integration); a joint that snaps a badly
     // misaligned body round can turn it by radians in one go and gets the exact normalisation
     const float k = n2 < 1.01f ? 1.5f - 0.5f * n2 : 1.f / sqrtf(n2);

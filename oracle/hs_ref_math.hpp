@@ -7,7 +7,10 @@
 // pinned commit unknown).  This file is a clean-room restatement of the semantics visible at
 // the call sites (src/sim.cpp, src/level_gen.cpp).  All float code here must be compiled
 // with -ffp-contract=off: the HIP product evaluates the same expression trees in the same
-// order so results agree bit for bit.
+// order so results agree bit for bit.  The vector / quaternion helpers below use FUSED
+// multiply-adds, written out one by one (hs_fma: one rounding, the same on both machines) —
+// as a CUDA build of the reference does by default (nvcc --fmad=true), though which of its
+// operations that fuses is as unknowable as the rest of the engine's arithmetic.
 #pragma once
 #include <cstdint>
 #include <cmath>
@@ -25,9 +28,10 @@ static inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
 static inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 static inline V3 operator*(float s, V3 a) { return {a.x * s, a.y * s, a.z * s}; }
 static inline V3 mulc(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-static inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float hs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline float dot(V3 a, V3 b) { return hs_fma(a.z, b.z, hs_fma(a.y, b.y, a.x * b.x)); }
 static inline V3 cross(V3 a, V3 b) {
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return {hs_fma(a.y, b.z, -(a.z * b.y)), hs_fma(a.z, b.x, -(a.x * b.z)), hs_fma(a.x, b.y, -(a.y * b.x))};
 }
 static inline float len2(V3 a) { return dot(a, a); }
 static inline float len(V3 a) { return sqrtf(dot(a, a)); }
@@ -38,15 +42,15 @@ static inline float getc(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.
 // ---- quaternions (w,x,y,z), madrona::math::Quat call sites sim.cpp:225,350,408-409,469 ----
 static inline Q qmul(Q a, Q b) {
     return {
-        (a.w * b.w - a.x * b.x) - (a.y * b.y + a.z * b.z),
-        (a.w * b.x + a.x * b.w) + (a.y * b.z - a.z * b.y),
-        (a.w * b.y - a.x * b.z) + (a.y * b.w + a.z * b.x),
-        (a.w * b.z + a.x * b.y) - (a.y * b.x - a.z * b.w),
+        hs_fma(-a.z, b.z, hs_fma(-a.y, b.y, hs_fma(-a.x, b.x, a.w * b.w))),
+        hs_fma(-a.z, b.y, hs_fma(a.y, b.z, hs_fma(a.x, b.w, a.w * b.x))),
+        hs_fma(a.z, b.x, hs_fma(a.y, b.w, hs_fma(-a.x, b.z, a.w * b.y))),
+        hs_fma(a.z, b.w, hs_fma(-a.y, b.x, hs_fma(a.x, b.y, a.w * b.z))),
     };
 }
 static inline Q qinv(Q q) { return {q.w, -q.x, -q.y, -q.z}; }  // unit quaternions: conjugate
 static inline Q qnormalize(Q q) {
-    float n2 = (q.w * q.w + q.x * q.x) + (q.y * q.y + q.z * q.z);
+    float n2 = hs_fma(q.z, q.z, hs_fma(q.y, q.y, hs_fma(q.x, q.x, q.w * q.w)));
     float inv = 1.f / sqrtf(n2);
     return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
@@ -55,11 +59,11 @@ static inline V3 qrot(Q q, V3 v) {
     V3 p = {q.x, q.y, q.z};
     float s = q.w;
     float d2 = 2.f * dot(p, v);
-    float k = 2.f * s * s - 1.f;
-    V3 c = cross(p, v);
     float s2 = 2.f * s;
-    return {(d2 * p.x + k * v.x) + s2 * c.x, (d2 * p.y + k * v.y) + s2 * c.y,
-            (d2 * p.z + k * v.z) + s2 * c.z};
+    float k = hs_fma(s2, s, -1.f);
+    V3 c = cross(p, v);
+    return {hs_fma(s2, c.x, hs_fma(d2, p.x, k * v.x)), hs_fma(s2, c.y, hs_fma(d2, p.y, k * v.y)),
+            hs_fma(s2, c.z, hs_fma(d2, p.z, k * v.z))};
 }
 
 // ---- deterministic transcendental functions (shared formulas with the HIP product) ----
