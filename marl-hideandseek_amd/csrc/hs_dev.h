@@ -82,6 +82,9 @@ HSD V3 mulc(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 HSD float hs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 HSD float dot(V3 a, V3 b) { return hs_fma(a.z, b.z, hs_fma(a.y, b.y, a.x * b.x)); }
 HSD V3 cross(V3 a, V3 b) { return {hs_fma(a.y, b.z, -(a.z * b.y)), hs_fma(a.z, b.x, -(a.x * b.z)), hs_fma(a.x, b.y, -(a.y * b.x))}; }
+// a + b * s and a - b * s, each component one fused multiply-add
+HSD V3 madd(V3 a, V3 b, float s) { return {hs_fma(b.x, s, a.x), hs_fma(b.y, s, a.y), hs_fma(b.z, s, a.z)}; }
+HSD V3 nmadd(V3 a, V3 b, float s) { return {hs_fma(-b.x, s, a.x), hs_fma(-b.y, s, a.y), hs_fma(-b.z, s, a.z)}; }
 HSD float len2(V3 a) { return dot(a, a); }
 HSD float len(V3 a) { return sqrtf(dot(a, a)); }
 HSD V3 normalize(V3 a) { float inv = 1.f / len(a); return a * inv; }

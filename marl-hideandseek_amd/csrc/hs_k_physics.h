@@ -296,13 +296,13 @@ template <class OR> HSD void integrate_body(OR &R, BodyReg &b, int slot, int g, 
         const float h = kSubstepH;
         const float invM = obj_inv_mass(obj);
         const V3 invI = obj_inv_inertia(obj);
-        lin = lin + (force * invM + V3{0.f, 0.f, kGravityZ}) * h;
-        pos = pos + lin * h;
+        lin = madd(lin, madd(V3{0.f, 0.f, kGravityZ}, force, invM), h);
+        pos = madd(pos, lin, h);
         Q qi = qinv(rot);
         V3 wloc = qrot(qi, ang), tl = qrot(qi, V3{0.f, 0.f, torque});
         const V3 I = obj_inertia(obj);            // 1 / invI per axis, 0 where invI is 0
         V3 Iw = mulc(I, wloc);
-        wloc = wloc + mulc(invI, tl - cross(wloc, Iw)) * h;
+        wloc = madd(wloc, mulc(invI, tl - cross(wloc, Iw)), h);
         ang = qrot(rot, wloc);
         rot = quat_add_rotation(rot, ang * h);
         rst3(R.pos, slot, g, pos); rst4(R.rot, slot, g, rot);
@@ -936,8 +936,8 @@ HSD float pair_point_position(BodyS &me, bool isA, V3 n, V3 rl, float muS) {
     auto apply = [&](V3 p) {
         if (!has_mass(me)) return;
         const V3 dth = apply_inv_inertia(me, cross(rw, p));
-        if (isA) { me.pos = me.pos - p * me.invM; me.rot = quat_add_rotation(me.rot, -dth); }
-        else { me.pos = me.pos + p * me.invM; me.rot = quat_add_rotation(me.rot, dth); }
+        if (isA) { me.pos = nmadd(me.pos, p, me.invM); me.rot = quat_add_rotation(me.rot, -dth); }
+        else { me.pos = madd(me.pos, p, me.invM); me.rot = quat_add_rotation(me.rot, dth); }
     };
     apply(n * lam);
     rw = qrot(me.rot, rl);
@@ -945,7 +945,7 @@ HSD float pair_point_position(BodyS &me, bool isA, V3 n, V3 rl, float muS) {
     const V3 mv = pm - pprev;                                     // how far this side's point has moved in the substep
     const V3 ov = swap1(mv);
     const V3 dp = isA ? mv - ov : ov - mv;                        // (pA - pAprev) - (pB - pBprev)
-    const V3 dpt = dp - n * dot(dp, n);
+    const V3 dpt = nmadd(dp, n, dot(dp, n));
     const float lt2 = len2(dpt);
     if (lt2 > 1e-12f) {
         const float wt = gen_inv_mass_sq(me, rw, dpt, lt2);
@@ -971,13 +971,13 @@ HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float
     if (hA) v = vA;
     if (hB) v = v - vB;
     const float vn = dot(n, v);
-    const V3 vt = v - n * vn;
+    const V3 vt = nmadd(v, n, vn);
     const float vt2 = len2(vt);
     V3 dv = -(n * vn);
     if (vt2 > 1e-18f) {
         const float vtl = sqrtf(vt2);
         const float mag = fminf((muD * lamN) * kInvSubstepH, vtl);
-        dv = dv - vt * (mag / vtl);
+        dv = nmadd(dv, vt, mag / vtl);
     }
     const float dv2 = len2(dv);
     if (!(dv2 > 1e-18f)) return;
@@ -987,8 +987,8 @@ HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float
     if (!(ws > 0.f)) return;
     const V3 p = dv * (dv2 / ws);
     const V3 da = apply_inv_inertia(me, cross(rw, p));
-    if (isA) { me.lin = me.lin + p * me.invM; me.ang = me.ang + da; }
-    else { me.lin = me.lin - p * me.invM; me.ang = me.ang - da; }
+    if (isA) { me.lin = madd(me.lin, p, me.invM); me.ang = me.ang + da; }
+    else { me.lin = nmadd(me.lin, p, me.invM); me.ang = me.ang - da; }
 }
 
 template <bool POS, bool SPILL, class OR>

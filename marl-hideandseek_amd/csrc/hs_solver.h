@@ -53,7 +53,7 @@ HSD V3 apply_inv_inertia(const BodyS &b, V3 v) { return sym_mul(b.Iw, v); }
 // corrections skip the sqrt / divide of normalising the tangent (same expressions as the oracle's)
 HSD float gen_inv_mass_sq(const BodyS &b, V3 r, V3 d, float d2) {
     V3 rd = cross(r, d);
-    return b.invM * d2 + dot(rd, sym_mul(b.Iw, rd));
+    return hs_fma(b.invM, d2, dot(rd, sym_mul(b.Iw, rd)));
 }
 HSD float gen_inv_mass(const BodyS &b, V3 r, V3 n) {
     V3 rn = cross(r, n);
@@ -74,12 +74,12 @@ HSD bool has_mass(const BodyS &b) { return b.invM != 0.f || b.invI.z != 0.f || b
 template <bool HAS_B>
 HSD void apply_pos_impulse(BodyS &A, V3 rA, BodyS &B, V3 rB, V3 p) {
     if (has_mass(A)) {
-        A.pos = A.pos - p * A.invM;
+        A.pos = nmadd(A.pos, p, A.invM);
         V3 dth = apply_inv_inertia(A, cross(rA, p));
         A.rot = quat_add_rotation(A.rot, -dth);
     }
     if (HAS_B && has_mass(B)) {
-        B.pos = B.pos + p * B.invM;
+        B.pos = madd(B.pos, p, B.invM);
         V3 dth = apply_inv_inertia(B, cross(rB, p));
         B.rot = quat_add_rotation(B.rot, dth);
     }
@@ -117,7 +117,7 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
     } else {
         dp = pA - pAprev;
     }
-    V3 dpt = dp - n * dot(dp, n);
+    V3 dpt = nmadd(dp, n, dot(dp, n));
     float lt2 = len2(dpt);
     if (lt2 > 1e-12f) {
         float wtA = gen_inv_mass_sq(A, rAw, dpt, lt2);
@@ -161,7 +161,7 @@ HSD float solve_point_position_ground(BodyS &A, V3 n, V3 rAl, float offB, float 
         lam = share;
     }
     const V3 dp = pA - pAprev;
-    const V3 dpt = dp - n * dot(dp, n);
+    const V3 dpt = nmadd(dp, n, dot(dp, n));
     const float lt2 = len2(dpt);
     if (lt2 > 1e-12f) {
         const float wts = gen_inv_mass_sq(A, rAw, dpt, lt2);
@@ -200,7 +200,7 @@ HSD float yaw_ground_prepass(BodyS &A, V3 n, int np, V3 r0, V3 r1, V3 r2, V3 r3,
         return 0.f;
     }
     const float lamT = dmax / A.invM;
-    A.pos = A.pos - (n * lamT) * A.invM;
+    A.pos = nmadd(A.pos, n * lamT, A.invM);
     return lamT / (float)k;
 }
 
@@ -214,13 +214,13 @@ HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float la
     if (A.invM + A.invI.x + A.invI.y + A.invI.z != 0.f) v = A.lin + cross(A.ang, rAw);
     if (HAS_B && B.invM + B.invI.x + B.invI.y + B.invI.z != 0.f) v = v - (B.lin + cross(B.ang, rBw));
     float vn = dot(n, v);
-    V3 vt = v - n * vn;
+    V3 vt = nmadd(v, n, vn);
     float vt2 = len2(vt);
     V3 dv = -(n * vn);
     if (vt2 > 1e-18f) {
         float vtl = sqrtf(vt2);
         float mag = fminf((muD * lamN) * kInvSubstepH, vtl);
-        dv = dv - vt * (mag / vtl);
+        dv = nmadd(dv, vt, mag / vtl);
     }
     float dv2 = len2(dv);
     if (!(dv2 > 1e-18f)) return;
@@ -229,10 +229,10 @@ HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float la
     float ws = wA + wB;
     if (!(ws > 0.f)) return;
     V3 p = dv * (dv2 / ws);
-    A.lin = A.lin + p * A.invM;
+    A.lin = madd(A.lin, p, A.invM);
     A.ang = A.ang + apply_inv_inertia(A, cross(rAw, p));
     if (HAS_B) {
-        B.lin = B.lin - p * B.invM;
+        B.lin = nmadd(B.lin, p, B.invM);
         B.ang = B.ang - apply_inv_inertia(B, cross(rBw, p));
     }
 }

@@ -33,6 +33,9 @@ static inline float dot(V3 a, V3 b) { return hs_fma(a.z, b.z, hs_fma(a.y, b.y, a
 static inline V3 cross(V3 a, V3 b) {
     return {hs_fma(a.y, b.z, -(a.z * b.y)), hs_fma(a.z, b.x, -(a.x * b.z)), hs_fma(a.x, b.y, -(a.y * b.x))};
 }
+// a + b * s and a - b * s, each component one fused multiply-add
+static inline V3 madd(V3 a, V3 b, float s) { return {hs_fma(b.x, s, a.x), hs_fma(b.y, s, a.y), hs_fma(b.z, s, a.z)}; }
+static inline V3 nmadd(V3 a, V3 b, float s) { return {hs_fma(-b.x, s, a.x), hs_fma(-b.y, s, a.y), hs_fma(-b.z, s, a.z)}; }
 static inline float len2(V3 a) { return dot(a, a); }
 static inline float len(V3 a) { return sqrtf(dot(a, a)); }
 // (madrona Vector3::normalize, used at sim.cpp:591,733,786) — v * (1/len)

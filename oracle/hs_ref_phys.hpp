@@ -386,7 +386,7 @@ static inline V3 apply_inv_inertia(const BodyMass &bm, V3 v) { return sym_mul(bm
 // normalise the tangent: correction along t = d/|d| of size |d| / w(t) equals d * (|d|^2 / w'(d)).
 static inline float gen_inv_mass_sq(const BodyMass &bm, V3 r, V3 d, float d2) {
     V3 rd = cross(r, d);
-    return bm.invM * d2 + dot(rd, sym_mul(bm.Iw, rd));
+    return hs_fma(bm.invM, d2, dot(rd, sym_mul(bm.Iw, rd)));
 }
 static inline float gen_inv_mass(const BodyMass &bm, V3 r, V3 n) {
     V3 rn = cross(r, n);
@@ -410,12 +410,12 @@ static inline Q quat_add_rotation(Q q, V3 dth) {
 static inline void apply_pos_impulse(DBody *A, const BodyMass &ma, V3 rA, DBody *B, const BodyMass &mb,
                                      V3 rB, V3 p) {
     if (ma.invM != 0.f || ma.invI.z != 0.f || ma.invI.x != 0.f || ma.invI.y != 0.f) {
-        A->pos = A->pos - p * ma.invM;
+        A->pos = nmadd(A->pos, p, ma.invM);
         V3 dth = apply_inv_inertia(ma, cross(rA, p));
         A->rot = quat_add_rotation(A->rot, -dth);
     }
     if (B && (mb.invM != 0.f || mb.invI.z != 0.f || mb.invI.x != 0.f || mb.invI.y != 0.f)) {
-        B->pos = B->pos + p * mb.invM;
+        B->pos = madd(B->pos, p, mb.invM);
         V3 dth = apply_inv_inertia(mb, cross(rB, p));
         B->rot = quat_add_rotation(B->rot, dth);
     }
@@ -461,7 +461,7 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
         } else {
             dp = pA - pAprev;
         }
-        V3 dpt = dp - n * dot(dp, n);
+        V3 dpt = nmadd(dp, n, dot(dp, n));
         float lt2 = len2(dpt);
         if (lt2 > 1e-12f) {
             float wtA = gen_inv_mass_sq(ma, rAw, dpt, lt2);
@@ -505,14 +505,14 @@ static inline void solve_ground_positions_yaw_only(World &w, Manifold &m) {
     }
     if (k == 0 || !(ma.invM > 0.f)) return;
     const float lamT = dmax / ma.invM;
-    A->pos = A->pos - (n * lamT) * ma.invM;
+    A->pos = nmadd(A->pos, n * lamT, ma.invM);
     const float share = lamT / (float)k;
     for (int j = 0; j < m.np; ++j) {
         if (!(dj[j] > 0.f)) continue;
         m.lambdaN[j] += share;
         V3 rAw = qrot(A->rot, m.rA[j]);
         V3 dp = (A->pos + rAw) - pAprev[j];
-        V3 dpt = dp - n * dot(dp, n);
+        V3 dpt = nmadd(dp, n, dot(dp, n));
         float lt2 = len2(dpt);
         if (lt2 > 1e-12f) {
             float wts = gen_inv_mass_sq(ma, rAw, dpt, lt2);
@@ -527,10 +527,10 @@ static inline bool yaw_only(int32_t obj) { V3 i = obj_inv_inertia(obj); return i
 
 static inline void apply_vel_impulse(DBody *A, const BodyMass &ma, V3 rA, DBody *B, const BodyMass &mb,
                                      V3 rB, V3 p) {   // A gets +p, B gets -p
-    A->lin = A->lin + p * ma.invM;
+    A->lin = madd(A->lin, p, ma.invM);
     A->ang = A->ang + apply_inv_inertia(ma, cross(rA, p));
     if (B) {
-        B->lin = B->lin - p * mb.invM;
+        B->lin = nmadd(B->lin, p, mb.invM);
         B->ang = B->ang - apply_inv_inertia(mb, cross(rB, p));
     }
 }
@@ -551,14 +551,14 @@ static inline void solve_manifold_velocities(World &w, const Manifold &m) {
         if (ma.invM + ma.invI.x + ma.invI.y + ma.invI.z != 0.f) v = A->lin + cross(A->ang, rAw);
         if (B && mb.invM + mb.invI.x + mb.invI.y + mb.invI.z != 0.f) v = v - (B->lin + cross(B->ang, rBw));
         float vn = dot(n, v);
-        V3 vt = v - n * vn;
+        V3 vt = nmadd(v, n, vn);
         float vt2 = len2(vt);
         V3 dv = -(n * vn);                      // restitution 0: kill the normal component
         if (vt2 > 1e-18f) {
             // dynamic friction: |dv_t| <= h * muD * f_n with f_n = lamN / h^2, i.e. muD * lamN / h
             float vtl = sqrtf(vt2);
             float mag = fminf((m.muD * lamN) * kInvSubstepH, vtl);
-            dv = dv - vt * (mag / vtl);
+            dv = nmadd(dv, vt, mag / vtl);
         }
         float dv2 = len2(dv);
         if (!(dv2 > 1e-18f)) continue;
@@ -617,14 +617,14 @@ static inline void integrate_body(DBody &b) {
     if (b.objType == OBJ_NONE || b.response != RESP_DYNAMIC) return;
     float invM = obj_inv_mass(b.objType);
     V3 invI = obj_inv_inertia(b.objType);
-    b.lin = b.lin + (b.extForce * invM + V3{0.f, 0.f, kGravityZ}) * h;
-    b.pos = b.pos + b.lin * h;
+    b.lin = madd(b.lin, madd(V3{0.f, 0.f, kGravityZ}, b.extForce, invM), h);
+    b.pos = madd(b.pos, b.lin, h);
     Q qi = qinv(b.rot);
     V3 wl = qrot(qi, b.ang), tl = qrot(qi, b.extTorque);
     V3 I = {invI.x > 0.f ? 1.f / invI.x : 0.f, invI.y > 0.f ? 1.f / invI.y : 0.f,
             invI.z > 0.f ? 1.f / invI.z : 0.f};
     V3 Iw = mulc(I, wl);
-    wl = wl + mulc(invI, tl - cross(wl, Iw)) * h;
+    wl = madd(wl, mulc(invI, tl - cross(wl, Iw)), h);
     b.ang = qrot(b.rot, wl);
     b.rot = quat_add_rotation(b.rot, b.ang * h);
 }
