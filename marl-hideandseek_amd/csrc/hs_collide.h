@@ -85,7 +85,7 @@ HSD V3 hull_v(const HullRef &h, int i) {
     V3 l;
     if (h.kind == HULL_WEDGE) l = wedge_local_v(i);
     else l = {(i & 1) ? h.e.x : -h.e.x, (i & 2) ? h.e.y : -h.e.y, (i & 4) ? h.e.z : -h.e.z};
-    return ((h.c + h.ax * l.x) + h.ay * l.y) + h.az * l.z;
+    return madd(madd(madd(h.c, h.ax, l.x), h.ay, l.y), h.az, l.z);
 }
 HSD V3 hull_fn(const HullRef &h, int f) {
     if (h.kind == HULL_WEDGE) {

@@ -141,13 +141,12 @@ static inline Q quat_angle_axis_z(float angle) {
 // ---- 3x3 rotation (columns) from a unit quaternion ----
 struct M3 { V3 c0, c1, c2; };
 static inline M3 m3_from_quat(Q q) {
-    float x2 = q.x * q.x, y2 = q.y * q.y, z2 = q.z * q.z;
+    float y2 = q.y * q.y, z2 = q.z * q.z;
     float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
-    float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
     M3 m;
-    m.c0 = {1.f - 2.f * (y2 + z2), 2.f * (xy + wz), 2.f * (xz - wy)};
-    m.c1 = {2.f * (xy - wz), 1.f - 2.f * (x2 + z2), 2.f * (yz + wx)};
-    m.c2 = {2.f * (xz + wy), 2.f * (yz - wx), 1.f - 2.f * (x2 + y2)};
+    m.c0 = {hs_fma(-2.f, hs_fma(q.y, q.y, z2), 1.f), 2.f * hs_fma(q.w, q.z, xy), 2.f * hs_fma(-q.w, q.y, xz)};
+    m.c1 = {2.f * hs_fma(-q.w, q.z, xy), hs_fma(-2.f, hs_fma(q.x, q.x, z2), 1.f), 2.f * hs_fma(q.w, q.x, yz)};
+    m.c2 = {2.f * hs_fma(q.w, q.y, xz), 2.f * hs_fma(-q.w, q.x, yz), hs_fma(-2.f, hs_fma(q.x, q.x, y2), 1.f)};
     return m;
 }
 

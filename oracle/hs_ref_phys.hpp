@@ -110,7 +110,7 @@ static inline void hull_box(Hull &h, V3 c, V3 ax, V3 ay, V3 az, V3 e) {
     h.center = c; h.is_box = true; h.ax = ax; h.ay = ay; h.az = az; h.e = e;
     for (int i = 0; i < 8; ++i) {
         float sx = (i & 1) ? e.x : -e.x, sy = (i & 2) ? e.y : -e.y, sz = (i & 4) ? e.z : -e.z;
-        h.v[i] = ((c + ax * sx) + ay * sy) + az * sz;
+        h.v[i] = madd(madd(madd(c, ax, sx), ay, sy), az, sz);
     }
     h.fn[0] = -ax; h.fn[1] = ax; h.fn[2] = -ay; h.fn[3] = ay; h.fn[4] = -az; h.fn[5] = az;
     for (int f = 0; f < 6; ++f) { h.fcnt[f] = 4; for (int k = 0; k < 4; ++k) h.fidx[f][k] = kBoxFaceIdx[f][k]; }
@@ -123,7 +123,7 @@ static inline void hull_wedge(Hull &h, V3 c, const M3 &m) {
     h.nv = 6; h.nf = 5; h.ned = 4; h.ne = 9;
     h.center = c; h.is_box = false; h.ax = m.c0; h.ay = m.c1; h.az = m.c2; h.e = {1.f, 1.f, 1.f};
     for (int i = 0; i < 6; ++i)
-        h.v[i] = ((c + m.c0 * kWedgeV[i][0]) + m.c1 * kWedgeV[i][1]) + m.c2 * kWedgeV[i][2];
+        h.v[i] = madd(madd(madd(c, m.c0, kWedgeV[i][0]), m.c1, kWedgeV[i][1]), m.c2, kWedgeV[i][2]);
     for (int f = 0; f < 5; ++f) {
         h.fn[f] = (m.c0 * kWedgeFN[f][0] + m.c1 * kWedgeFN[f][1]) + m.c2 * kWedgeFN[f][2];
         h.fcnt[f] = kWedgeFaceCnt[f];
