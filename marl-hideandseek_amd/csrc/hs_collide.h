@@ -173,7 +173,7 @@ HSD void hull_aabb(const HullRef &h, V3 *lo_out, V3 *hi_out) {
 struct RawManifold { V3 n; int np; V3 pA[4]; V3 pB[4]; int vidx[4]; };
 
 HSD float box_radius(const HullRef &h, V3 n) {
-    return (fabsf(dot(n, h.ax)) * h.e.x + fabsf(dot(n, h.ay)) * h.e.y) + fabsf(dot(n, h.az)) * h.e.z;
+    return hs_fma(fabsf(dot(n, h.az)), h.e.z, hs_fma(fabsf(dot(n, h.ay)), h.e.y, fabsf(dot(n, h.ax)) * h.e.x));
 }
 // The wedge's six world vertices, computed once per convex test (its supports walk them ~46 times).
 struct WedgeVerts { V3 v[6]; };
@@ -322,7 +322,7 @@ HSD int clip_face_contact(const HullRef &R, int fr, V3 nr, const HullRef &I, con
             bool in_prev = dprev <= 0.f, in_cur = dcur <= 0.f;
             if (in_prev != in_cur) {
                 float t = dprev / (dprev - dcur);
-                if (m < 8) { cb_set(cb, dst, m, prev + (cur - prev) * t); m++; }
+                if (m < 8) { cb_set(cb, dst, m, madd(prev, cur - prev, t)); m++; }
             }
             if (in_cur) { if (m < 8) { cb_set(cb, dst, m, cur); m++; } }
             prev = cur; dprev = dcur;
@@ -561,7 +561,7 @@ HSD bool sat_contact(const HullSrc &sa, const HullSrc &sb, const AxisResult &res
     m.n = refB ? -nr : nr; m.np = c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (i < c) {
-        const V3 on_ref = pinc[i] - nr * dist[i];
+        const V3 on_ref = nmadd(pinc[i], nr, dist[i]);
         m.pA[i] = refB ? pinc[i] : on_ref;
         m.pB[i] = refB ? on_ref : pinc[i];
     }

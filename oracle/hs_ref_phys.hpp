@@ -200,7 +200,7 @@ static inline bool collide_hull_plane(const Hull &A, V3 pn, float pd, RawManifol
 
 // Boxes: centre projection -/+ projected radius; the wedge walks its 6 vertices.
 static inline float box_radius(const Hull &h, V3 n) {
-    return (fabsf(dot(n, h.ax)) * h.e.x + fabsf(dot(n, h.ay)) * h.e.y) + fabsf(dot(n, h.az)) * h.e.z;
+    return hs_fma(fabsf(dot(n, h.az)), h.e.z, hs_fma(fabsf(dot(n, h.ay)), h.e.y, fabsf(dot(n, h.ax)) * h.e.x));
 }
 static inline float support_min(const Hull &h, V3 n) {
     if (h.is_box) return dot(n, h.center) - box_radius(h, n);
@@ -248,7 +248,7 @@ static inline int clip_face_contact(const Hull &R, int fr, const Hull &I, V3 *pI
             bool in_prev = dprev <= 0.f, in_cur = dcur <= 0.f;
             if (in_prev != in_cur) {
                 float t = dprev / (dprev - dcur);
-                if (m < 8) tmp[m++] = prev + (cur - prev) * t;
+                if (m < 8) tmp[m++] = madd(prev, cur - prev, t);
             }
             if (in_cur) { if (m < 8) tmp[m++] = cur; }
             prev = cur; dprev = dcur;
@@ -339,13 +339,13 @@ static inline bool collide_hulls(const Hull &A, const Hull &B, RawManifold &m) {
         if (c == 0) return false;
         V3 nr = B.fn[fb];
         m.n = -nr; m.np = c;
-        for (int i = 0; i < c; ++i) { m.pA[i] = pinc[i]; m.pB[i] = pinc[i] - nr * dist[i]; }
+        for (int i = 0; i < c; ++i) { m.pA[i] = pinc[i]; m.pB[i] = nmadd(pinc[i], nr, dist[i]); }
     } else {
         int c = clip_face_contact(A, fa, B, pinc, dist);
         if (c == 0) return false;
         V3 nr = A.fn[fa];
         m.n = nr; m.np = c;
-        for (int i = 0; i < c; ++i) { m.pB[i] = pinc[i]; m.pA[i] = pinc[i] - nr * dist[i]; }
+        for (int i = 0; i < c; ++i) { m.pB[i] = pinc[i]; m.pA[i] = nmadd(pinc[i], nr, dist[i]); }
     }
     return true;
 }
