@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(HS_OBS_
         for (int b = 0; b < kNumDSlots; ++b) {
             if (!((others >> b) & 1u)) continue;
             const float4 e = *reinterpret_cast<const float4 *>(relI + b * 8);
-            const float bb = e.x * d.x + e.y * d.y + e.z * d.z, cc = e.w;
+            const float bb = hs_fma(e.z, d.z, hs_fma(e.y, d.y, e.x * d.x)), cc = e.w;      // (= dot(origin - centre, d))
             // culled: cc > 0 && (bb > 0 || bb * bb < dd2 * cc * 0.999f) — as lane masks (ordered comparisons 2 = ">",
             // 4 = "<"; 32 = integer "=="), combined by scalar instructions
             unsigned long long m = __builtin_amdgcn_fcmpf(cc, 0.f, 2) &
