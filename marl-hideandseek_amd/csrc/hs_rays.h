@@ -44,8 +44,8 @@ HSD float ray_box_local(V3 o, V3 d, V3 e) {
         if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) miss = true; continue; }
         // slab in centre / extent form: entry = -o/d - e/|d|, exit = -o/d + e/|d| (no near/far swap)
         float inv = 1.f / dd[k];
-        float c = (-oo[k]) * inv, r = ee[k] * fabsf(inv);
-        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
+        const float r = ee[k] * fabsf(inv);                 // entry = -o/d - e/|d|, exit = -o/d + e/|d|, each one fused multiply-add
+        tn = fmaxf(tn, hs_fma(-oo[k], inv, -r)); tf = fminf(tf, hs_fma(-oo[k], inv, r));
     }
     if (miss || tn > tf || tn < 0.f) return -1.f;
     return tn;
@@ -78,8 +78,8 @@ HSD float ray_wall(V3 o, V3 d, V3 inv, V3 e) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) miss = true; continue; }
-        float c = (-oo[k]) * ii[k], r = ee[k] * fabsf(ii[k]);
-        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
+        const float r = ee[k] * fabsf(ii[k]);                 // entry = -o/d - e/|d|, exit = -o/d + e/|d|, each one fused multiply-add
+        tn = fmaxf(tn, hs_fma(-oo[k], ii[k], -r)); tf = fminf(tf, hs_fma(-oo[k], ii[k], r));
     }
     if (miss || tn > tf || tn < 0.f) return -1.f;
     return tn;
@@ -93,8 +93,8 @@ HSD WallZ ray_wall_z(float oz, float dz, float invz) {
     WallZ z = {-3.0e38f, 3.0e38f, false};
     const float o = oz - 1.25f, e = 1.25f;
     if (dz == 0.f) { z.miss = o < -e || o > e; return z; }
-    float c = (-o) * invz, r = e * fabsf(invz);
-    z.tn = fmaxf(z.tn, c - r); z.tf = fminf(z.tf, c + r);
+    const float r = e * fabsf(invz);                 // entry = -o/d - e/|d|, exit = -o/d + e/|d|, each one fused multiply-add
+    z.tn = fmaxf(z.tn, hs_fma(-o, invz, -r)); z.tf = fminf(z.tf, hs_fma(-o, invz, r));
     return z;
 }
 HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, WallZ z) {
@@ -102,13 +102,13 @@ HSD float ray_wall_xy(float ox, float oy, V3 d, V3 inv, float ex, float ey, Wall
     bool miss = z.miss;
     if (d.x == 0.f) { if (ox < -ex || ox > ex) miss = true; }
     else {
-        float c = (-ox) * inv.x, r = ex * fabsf(inv.x);
-        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
+        const float r = ex * fabsf(inv.x);                 // entry = -o/d - e/|d|, exit = -o/d + e/|d|, each one fused multiply-add
+        tn = fmaxf(tn, hs_fma(-ox, inv.x, -r)); tf = fminf(tf, hs_fma(-ox, inv.x, r));
     }
     if (d.y == 0.f) { if (oy < -ey || oy > ey) miss = true; }
     else {
-        float c = (-oy) * inv.y, r = ey * fabsf(inv.y);
-        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
+        const float r = ey * fabsf(inv.y);                 // entry = -o/d - e/|d|, exit = -o/d + e/|d|, each one fused multiply-add
+        tn = fmaxf(tn, hs_fma(-oy, inv.y, -r)); tf = fminf(tf, hs_fma(-oy, inv.y, r));
     }
     tn = fmaxf(tn, z.tn); tf = fminf(tf, z.tf);
     if (miss || tn > tf || tn < 0.f) return -1.f;
@@ -134,8 +134,8 @@ struct WallScan {
     }
     // wall = (cx, cy, hx, hy)
     HSD void wall(f32x2 centre, f32x2 half, int id) {
-        const f32x2 c = (-(o - centre)) * inv, r = half * ainv;
-        const f32x2 lo = c - r, hi = c + r;
+        const f32x2 m = -(o - centre), r = half * ainv;
+        const f32x2 lo = __builtin_elementwise_fma(m, inv, -r), hi = __builtin_elementwise_fma(m, inv, r);
         const float tn = fmaxf(fmaxf(lo.x, lo.y), zn);
         const float tf = fminf(fminf(hi.x, hi.y), zf);
         const bool ok = (tn <= tf) & (tn >= 0.f) & (tn < best);
@@ -148,11 +148,9 @@ struct WallScan {
 // ray_box_local for a direction without zero components (decided once per wave).
 HSD float ray_box_local_nz(V3 o, V3 d, V3 e) {
     const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
-    const float cx = (-o.x) * ix, rx = e.x * fabsf(ix);
-    const float cy = (-o.y) * iy, ry = e.y * fabsf(iy);
-    const float cz = (-o.z) * iz, rz = e.z * fabsf(iz);
-    const float tn = fmaxf(fmaxf(fmaxf(-3.0e38f, cx - rx), cy - ry), cz - rz);
-    const float tf = fminf(fminf(fminf(3.0e38f, cx + rx), cy + ry), cz + rz);
+    const float rx = e.x * fabsf(ix), ry = e.y * fabsf(iy), rz = e.z * fabsf(iz);
+    const float tn = fmaxf(fmaxf(fmaxf(-3.0e38f, hs_fma(-o.x, ix, -rx)), hs_fma(-o.y, iy, -ry)), hs_fma(-o.z, iz, -rz));
+    const float tf = fminf(fminf(fminf(3.0e38f, hs_fma(-o.x, ix, rx)), hs_fma(-o.y, iy, ry)), hs_fma(-o.z, iz, rz));
     if (tn > tf || tn < 0.f) return -1.f;
     return tn;
 }

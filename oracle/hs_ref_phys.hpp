@@ -751,8 +751,8 @@ static inline float ray_box_local(V3 o, V3 d, V3 e) {
         if (dd[k] == 0.f) { if (oo[k] < -ee[k] || oo[k] > ee[k]) return -1.f; continue; }
         // slab in centre / extent form: entry = -o/d - e/|d|, exit = -o/d + e/|d| (no near/far swap)
         float inv = 1.f / dd[k];
-        float c = (-oo[k]) * inv, r = ee[k] * fabsf(inv);
-        tn = fmaxf(tn, c - r); tf = fminf(tf, c + r);
+        const float r = ee[k] * fabsf(inv);
+        tn = fmaxf(tn, hs_fma(-oo[k], inv, -r)); tf = fminf(tf, hs_fma(-oo[k], inv, r));
     }
     if (tn > tf || tn < 0.f) return -1.f;
     return tn;
