@@ -85,6 +85,11 @@ HSD V3 cross(V3 a, V3 b) { return {hs_fma(a.y, b.z, -(a.z * b.y)), hs_fma(a.z, b
 // a + b * s and a - b * s, each component one fused multiply-add
 HSD V3 madd(V3 a, V3 b, float s) { return {hs_fma(b.x, s, a.x), hs_fma(b.y, s, a.y), hs_fma(b.z, s, a.z)}; }
 HSD V3 nmadd(V3 a, V3 b, float s) { return {hs_fma(-b.x, s, a.x), hs_fma(-b.y, s, a.y), hs_fma(-b.z, s, a.z)}; }
+// a . b + c and a x b + c with every product fused
+HSD float dot_add(V3 a, V3 b, float c) { return hs_fma(a.z, b.z, hs_fma(a.y, b.y, hs_fma(a.x, b.x, c))); }
+HSD V3 cross_add(V3 a, V3 b, V3 c) {
+    return {hs_fma(a.y, b.z, hs_fma(-a.z, b.y, c.x)), hs_fma(a.z, b.x, hs_fma(-a.x, b.z, c.y)), hs_fma(a.x, b.y, hs_fma(-a.y, b.x, c.z))};
+}
 HSD float len2(V3 a) { return dot(a, a); }
 HSD float len(V3 a) { return sqrtf(dot(a, a)); }
 HSD V3 normalize(V3 a) { float inv = 1.f / len(a); return a * inv; }

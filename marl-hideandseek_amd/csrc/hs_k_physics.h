@@ -962,7 +962,7 @@ HSD void pair_point_velocity(BodyS &me, bool isA, V3 n, V3 rl, float lamN, float
     if (!(lamN > 0.f)) return;
     const V3 rw = qrot(me.rot, rl);
     const bool hm = me.invM + me.invI.x + me.invI.y + me.invI.z != 0.f;
-    const V3 vm = me.lin + cross(me.ang, rw);
+    const V3 vm = cross_add(me.ang, rw, me.lin);
     const V3 vo = swap1(vm);
     const bool ho = swap1(hm ? 1.f : 0.f) != 0.f;
     const V3 vA = isA ? vm : vo, vB = isA ? vo : vm;

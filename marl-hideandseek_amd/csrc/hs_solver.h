@@ -57,7 +57,7 @@ HSD float gen_inv_mass_sq(const BodyS &b, V3 r, V3 d, float d2) {
 }
 HSD float gen_inv_mass(const BodyS &b, V3 r, V3 n) {
     V3 rn = cross(r, n);
-    return b.invM + dot(rn, sym_mul(b.Iw, rn));
+    return dot_add(rn, sym_mul(b.Iw, rn), b.invM);
 }
 // q += 0.5 * (0,dth) * q, then one Newton step of 1/sqrt(|q|^2) from 1 (DESIGN.md "Engine decisions")
 HSD Q quat_add_rotation(Q q, V3 dth) {
@@ -66,7 +66,7 @@ HSD Q quat_add_rotation(Q q, V3 dth) {
     const float n2 = hs_fma(r.z, r.z, hs_fma(r.y, r.y, hs_fma(r.x, r.x, r.w * r.w)));
     // small updates (|dth| < 0.2 rad: every contact correction, ordinary integration); a joint that snaps a badly
     // misaligned body round can turn it by radians in one go and gets the exact normalisation
-    const float k = n2 < 1.01f ? 1.5f - 0.5f * n2 : 1.f / sqrtf(n2);
+    const float k = n2 < 1.01f ? hs_fma(-0.5f, n2, 1.5f) : 1.f / sqrtf(n2);
     return {r.w * k, r.x * k, r.y * k, r.z * k};
 }
 HSD bool has_mass(const BodyS &b) { return b.invM != 0.f || b.invI.z != 0.f || b.invI.x != 0.f || b.invI.y != 0.f; }
@@ -93,11 +93,11 @@ HSD float solve_point_position(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float o
     V3 pA = A.pos + rAw;
     V3 rBw = HAS_B ? qrot(B.rot, rBl) : V3{0.f, 0.f, 0.f};
     V3 pB = HAS_B ? B.pos + rBw : V3{0.f, 0.f, 0.f};
-    float d = HAS_B ? dot(pA - pB, n) : dot(pA, n) - offB;
+    float d = HAS_B ? dot(pA - pB, n) : dot_add(pA, n, -offB);
     if (!(d > 0.f)) return 0.f;
     V3 pAprev = A.ppos + qrot(A.prot, rAl);
     V3 pBprev = HAS_B ? B.ppos + qrot(B.prot, rBl) : V3{0.f, 0.f, 0.f};
-    float dprev = HAS_B ? dot(pAprev - pBprev, n) : dot(pAprev, n) - offB;
+    float dprev = HAS_B ? dot(pAprev - pBprev, n) : dot_add(pAprev, n, -offB);
     float excess = dprev - kMaxDepenVel * kSubstepH;
     if (excess > 0.f) d = d - excess;
     if (!(d > 0.f)) return 0.f;
@@ -144,9 +144,9 @@ HSD float solve_point_position_ground(BodyS &A, V3 n, V3 rAl, float offB, float 
     const V3 pAprev = A.ppos + qrot(A.prot, rAl);
     float lam;
     if (!yaw) {
-        float d = dot(pA, n) - offB;
+        float d = dot_add(pA, n, -offB);
         if (!(d > 0.f)) return 0.f;
-        const float dprev = dot(pAprev, n) - offB;
+        const float dprev = dot_add(pAprev, n, -offB);
         const float excess = dprev - kMaxDepenVel * kSubstepH;
         if (excess > 0.f) d = d - excess;
         if (!(d > 0.f)) return 0.f;
@@ -185,9 +185,9 @@ HSD float yaw_ground_prepass(BodyS &A, V3 n, int np, V3 r0, V3 r1, V3 r2, V3 r3,
         dj[j] = 0.f;
         if (j < np) {
             const V3 r = j == 0 ? r0 : j == 1 ? r1 : j == 2 ? r2 : r3;
-            float d = dot(A.pos + qrot(A.rot, r), n) - off;
+            float d = dot_add(A.pos + qrot(A.rot, r), n, -off);
             if (d > 0.f) {
-                const float excess = (dot(A.ppos + qrot(A.prot, r), n) - off) - kMaxDepenVel * kSubstepH;
+                const float excess = dot_add(A.ppos + qrot(A.prot, r), n, -off) - kMaxDepenVel * kSubstepH;
                 if (excess > 0.f) d = d - excess;
             }
             dj[j] = d;
@@ -211,8 +211,8 @@ HSD void solve_point_velocity(BodyS &A, BodyS &B, V3 n, V3 rAl, V3 rBl, float la
     V3 rAw = qrot(A.rot, rAl);
     V3 rBw = HAS_B ? qrot(B.rot, rBl) : V3{0.f, 0.f, 0.f};
     V3 v = {0.f, 0.f, 0.f};
-    if (A.invM + A.invI.x + A.invI.y + A.invI.z != 0.f) v = A.lin + cross(A.ang, rAw);
-    if (HAS_B && B.invM + B.invI.x + B.invI.y + B.invI.z != 0.f) v = v - (B.lin + cross(B.ang, rBw));
+    if (A.invM + A.invI.x + A.invI.y + A.invI.z != 0.f) v = cross_add(A.ang, rAw, A.lin);
+    if (HAS_B && B.invM + B.invI.x + B.invI.y + B.invI.z != 0.f) v = v - cross_add(B.ang, rBw, B.lin);
     float vn = dot(n, v);
     V3 vt = nmadd(v, n, vn);
     float vt2 = len2(vt);

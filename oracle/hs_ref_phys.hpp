@@ -390,7 +390,7 @@ static inline float gen_inv_mass_sq(const BodyMass &bm, V3 r, V3 d, float d2) {
 }
 static inline float gen_inv_mass(const BodyMass &bm, V3 r, V3 n) {
     V3 rn = cross(r, n);
-    return bm.invM + dot(rn, sym_mul(bm.Iw, rn));
+    return dot_add(rn, sym_mul(bm.Iw, rn), bm.invM);
 }
 // q += 0.5 * (0,dth) * q, then — for small updates — ONE Newton step of 1/sqrt(|q|^2) from 1 instead of an exact
 // normalisation:
@@ -403,7 +403,7 @@ static inline Q quat_add_rotation(Q q, V3 dth) {
     const float n2 = hs_fma(r.z, r.z, hs_fma(r.y, r.y, hs_fma(r.x, r.x, r.w * r.w)));
     // small updates (|dth| < 0.2 rad: every contact correction, ordinary integration); a joint that snaps a badly
     // misaligned body round can turn it by radians in one go and gets the exact normalisation
-    const float k = n2 < 1.01f ? 1.5f - 0.5f * n2 : 1.f / sqrtf(n2);
+    const float k = n2 < 1.01f ? hs_fma(-0.5f, n2, 1.5f) : 1.f / sqrtf(n2);
     return {r.w * k, r.x * k, r.y * k, r.z * k};
 }
 // positional impulse p applied at rA (on A, gets -p) and rB (on B, gets +p); r's are world offsets
@@ -432,14 +432,14 @@ static inline void solve_manifold_positions(World &w, Manifold &m) {
         V3 pA = A->pos + rAw;
         V3 rBw = B ? qrot(B->rot, m.rB[j]) : V3{0.f, 0.f, 0.f};
         V3 pB = B ? B->pos + rBw : V3{0.f, 0.f, 0.f};
-        float d = B ? dot(pA - pB, n) : dot(pA, n) - m.offB[j];
+        float d = B ? dot(pA - pB, n) : dot_add(pA, n, -m.offB[j]);
         if (!(d > 0.f)) continue;
         // Overlap that already existed at the start of the substep (spawn overlaps after 20
         // rejected placements, level_gen.cpp:146) is resolved at kMaxDepenVel instead of in one
         // substep; penetration gained during this substep is always resolved in full.
         V3 pAprev = A->prevPos + qrot(A->prevRot, m.rA[j]);
         V3 pBprev = B ? B->prevPos + qrot(B->prevRot, m.rB[j]) : V3{0.f, 0.f, 0.f};
-        float dprev = B ? dot(pAprev - pBprev, n) : dot(pAprev, n) - m.offB[j];
+        float dprev = B ? dot(pAprev - pBprev, n) : dot_add(pAprev, n, -m.offB[j]);
         float excess = dprev - kMaxDepenVel * kSubstepH;
         if (excess > 0.f) d = d - excess;
         if (!(d > 0.f)) continue;
@@ -494,10 +494,10 @@ static inline void solve_ground_positions_yaw_only(World &w, Manifold &m) {
     int k = 0; float dmax = 0.f;
     for (int j = 0; j < m.np; ++j) {
         V3 pA = A->pos + qrot(A->rot, m.rA[j]);
-        float d = dot(pA, n) - m.offB[j];
+        float d = dot_add(pA, n, -m.offB[j]);
         pAprev[j] = A->prevPos + qrot(A->prevRot, m.rA[j]);
         if (d > 0.f) {
-            float excess = (dot(pAprev[j], n) - m.offB[j]) - kMaxDepenVel * kSubstepH;
+            float excess = dot_add(pAprev[j], n, -m.offB[j]) - kMaxDepenVel * kSubstepH;
             if (excess > 0.f) d = d - excess;
         }
         dj[j] = d;
@@ -548,8 +548,8 @@ static inline void solve_manifold_velocities(World &w, const Manifold &m) {
         V3 rBw = B ? qrot(B->rot, m.rB[j]) : V3{0.f, 0.f, 0.f};
         // bodies with Static response keep a stale Velocity; it does not take part
         V3 v = {0.f, 0.f, 0.f};
-        if (ma.invM + ma.invI.x + ma.invI.y + ma.invI.z != 0.f) v = A->lin + cross(A->ang, rAw);
-        if (B && mb.invM + mb.invI.x + mb.invI.y + mb.invI.z != 0.f) v = v - (B->lin + cross(B->ang, rBw));
+        if (ma.invM + ma.invI.x + ma.invI.y + ma.invI.z != 0.f) v = cross_add(A->ang, rAw, A->lin);
+        if (B && mb.invM + mb.invI.x + mb.invI.y + mb.invI.z != 0.f) v = v - cross_add(B->ang, rBw, B->lin);
         float vn = dot(n, v);
         V3 vt = nmadd(v, n, vn);
         float vt2 = len2(vt);
