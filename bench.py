@@ -421,7 +421,7 @@ def main():
                                        "shorter than an episode: moved by untimed preroll steps so that preparation and "
                                        "post-preparation steps are in the episode's own proportion (95 : 145); no level regeneration "
                                        "inside, and the post-preparation steps are the first ones after the seekers' release, when the "
-                                       "contact load is still building up: about 7 % faster than whole episodes (28.8 M world-steps/s)")},
+                                       "contact load is still building up: about 7 % faster than whole episodes (32.4 M world-steps/s)")},
             "roofline": roofline,
         }
         out["device_status"] = status
