@@ -230,3 +230,15 @@ print("ORDER-OK")
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ORDER-OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_build_then_smoke_in_one_process():
+    """The driver calls __graft_entry__.build() and smoke() in separate processes; in ONE process build() must not bring
+    /opt/rocm's HIP runtime in ahead of torch's (its symbol and import checks run in child processes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "smoke OK" in out.stdout, out.stderr[-2000:]
